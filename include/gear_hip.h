@@ -1,0 +1,212 @@
+/*
+ * gear_hip.h — C ABI of the MI355X batched collision-validation engine.
+ *
+ * This is the drop-in boundary for gear's planning hot path.  The reference
+ * (openrr/gear) has no FFI of its own: the path is the Rust closure
+ * `|q| is_feasible(using_joints, q, objects)` handed to rrt::dual_rrt_connect /
+ * rrt::smooth_path (src/planner/joint_path_planner.rs:168-188, 221-241) plus
+ * the six public predicates at src/planner/joint_path_planner.rs:71-134 and
+ * CollisionChecker::check_env / check_self
+ * (src/collision/collision_checker.rs:268-287).  Each entry point below names
+ * the reference item it replaces.  A Rust `-sys` crate binds exactly these
+ * symbols.
+ *
+ * Conventions
+ *  - every function returns GH_OK (0) or a negative gh_status; nothing throws
+ *    across this boundary; gh_last_error() gives the text for the calling
+ *    thread's last failure;
+ *  - all buffers are caller-owned; `_dev` variants take device pointers and an
+ *    optional hipStream_t (as void*), the others take host pointers and are
+ *    synchronous;
+ *  - a gh_scene is immutable after creation and may be shared by host threads
+ *    (calls on one scene serialise on the scene's stream);
+ *  - scalars in descriptors are f64; `precision` (32|64) selects the arithmetic
+ *    type T of the whole path, converting exactly where the reference converts
+ *    (na::convert of URDF f64 values, src/collision/urdf.rs:18-27).
+ */
+#ifndef GEAR_HIP_H
+#define GEAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums ------------------------------------------------------------- */
+
+typedef enum gh_status {
+  GH_OK = 0,
+  GH_ERR_INVALID = -1,      /* malformed descriptor / null pointer            */
+  GH_ERR_DOF_MISMATCH = -2, /* cf. gear::Error::DofMismatch (errors.rs:48)    */
+  GH_ERR_HIP = -3,          /* a HIP runtime call failed                      */
+  GH_ERR_TOO_LARGE = -4,    /* scene exceeds a documented capacity            */
+  GH_ERR_NONCONVEX = -5,    /* mesh is not a closed convex polytope           */
+  GH_ERR_NO_DEVICE = -6     /* HIP device missing: the product never falls
+                               back to a CPU path                             */
+} gh_status;
+
+enum { GH_JOINT_FIXED = 0, GH_JOINT_ROTATIONAL = 1, GH_JOINT_LINEAR = 2 };
+
+/* urdf_geometry_to_shape_handle, src/collision/urdf.rs:10-73 */
+enum {
+  GH_SHAPE_BOX = 0,      /* Cuboid(half extents)            urdf.rs:18-25 */
+  GH_SHAPE_BALL = 1,     /* Ball(radius)                    urdf.rs:51-53 */
+  GH_SHAPE_CYLINDER = 2, /* 30-gon prism TriMesh, Z axis    urdf.rs:26-50 */
+  GH_SHAPE_MESH = 3      /* closed convex TriMesh           urdf.rs:54-71 */
+};
+
+/* per-configuration result byte */
+enum {
+  GH_FLAG_ENV = 1,  /* has_any_colliding            joint_path_planner.rs:86-98   */
+  GH_FLAG_SELF = 2, /* has_any_colliding_with_self  joint_path_planner.rs:123-128 */
+  GH_FLAG_LIMIT = 4 /* set_joint_positions Err(_)   joint_path_planner.rs:77-82   */
+};
+
+/* `what` argument: which predicates to evaluate */
+enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2 };
+
+/* ---- descriptors ------------------------------------------------------- */
+
+/* One k::Node.  Nodes are listed in k::Chain iteration order (depth-first,
+ * children visited in reverse insertion order; node 0 is the synthetic fixed
+ * "root" joint), which is the order EnvCollisionNames walks
+ * (collision_checker.rs:55,75). */
+typedef struct gh_node_desc {
+  int32_t parent;       /* index into nodes[], -1 for node 0                  */
+  int32_t joint_type;   /* GH_JOINT_*                                         */
+  double axis[3];       /* unit joint axis                                    */
+  double origin_t[3];   /* joint origin translation                           */
+  double origin_q[4];   /* joint origin rotation, unit quaternion (i,j,k,w)   */
+  int32_t has_limit;    /* 0: continuous or upper==lower                      */
+  int32_t mimic_parent; /* node index this joint mimics, -1 if none           */
+  double limit_lo, limit_hi;
+  double mimic_mult, mimic_offset;
+  double position;      /* current joint position (joints not in the batch)   */
+} gh_node_desc;
+
+typedef struct gh_shape_desc {
+  int32_t kind;     /* GH_SHAPE_*                                             */
+  int32_t node;     /* robot: owning node index; obstacle: ignored            */
+  double params[3]; /* box: half extents; ball: r; cylinder: r, length        */
+  double t[3];      /* pose translation: node-local (robot) / world (obstacle)*/
+  double q[4];      /* pose rotation (i,j,k,w)                                */
+  int32_t mesh;     /* GH_SHAPE_MESH: index into meshes[]; else -1            */
+  int32_t reserved;
+} gh_shape_desc;
+
+typedef struct gh_mesh_desc {
+  int32_t n_vertices;
+  int32_t n_triangles;
+  const double* vertices;   /* [n_vertices][3], shape-local                   */
+  const int32_t* triangles; /* [n_triangles][3]                               */
+} gh_mesh_desc;
+
+/* CollisionChecker + k::Chain flattened (collision_checker.rs:234-262). */
+typedef struct gh_robot_desc {
+  int32_t n_nodes;
+  int32_t n_cols;   /* D: dof of `using_joints`                               */
+  int32_t n_shapes; /* L                                                      */
+  int32_t n_pairs;  /* P                                                      */
+  int32_t n_meshes;
+  int32_t reserved;
+  const gh_node_desc* nodes;
+  const int32_t* col_node;     /* [n_cols] batch column -> node index, in
+                                  using_joints.iter_joints() order            */
+  const gh_shape_desc* shapes; /* ordered by node, then <collision> order     */
+  const int32_t* pairs;        /* [n_pairs][2] node indices (self pairs)      */
+  const gh_mesh_desc* meshes;
+} gh_robot_desc;
+
+/* Compound<f64>::from_urdf_robot flattened (collision_checker.rs:349-369);
+ * order = objects.shapes() order. */
+typedef struct gh_obstacle_desc {
+  int32_t n_shapes; /* O */
+  int32_t n_meshes;
+  const gh_shape_desc* shapes;
+  const gh_mesh_desc* meshes;
+} gh_obstacle_desc;
+
+typedef struct gh_scene gh_scene;
+
+/* instrumentation counters returned by gh_scene_counters (per scene, summed
+ * over every instrumented call since creation) */
+typedef struct gh_counters {
+  uint64_t configs;      /* configurations processed                          */
+  uint64_t pairs;        /* shape pairs considered (env + self)               */
+  uint64_t cull_pass;    /* pairs surviving the bounding-sphere cull          */
+  uint64_t sat_tests;    /* box-box SAT evaluations                           */
+  uint64_t exact_tests;  /* GJK margin queries                                */
+  uint64_t exact_iters;  /* GJK iterations                                    */
+  uint64_t reserved[2];
+} gh_counters;
+
+/* ---- entry points ------------------------------------------------------ */
+
+/* Replaces JointPathPlannerBuilder::finalize + CollisionChecker::from_urdf_robot
+ * + Compound::from_urdf_robot (joint_path_planner.rs:314-328,
+ * collision_checker.rs:234-262,349-369): flattens the robot and the obstacle
+ * compound into SoA tables resident in HBM on `device`. */
+int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacles,
+                    double margin, int precision, int device, gh_scene** out);
+void gh_scene_destroy(gh_scene* scene);
+
+int gh_scene_dof(const gh_scene* scene);       /* D  */
+int gh_scene_nodes(const gh_scene* scene);     /* N  */
+int gh_scene_precision(const gh_scene* scene); /* 32|64 */
+int gh_scene_device(const gh_scene* scene);
+
+/* Replaces the closure |q| is_feasible(..) / is_feasible_with_self(..) applied
+ * to n configurations (joint_path_planner.rs:71-84,113-121).
+ * q: [n][D] row-major, float or double per scene precision.
+ * flags[i]: GH_FLAG_* bits; a limit violation yields GH_FLAG_LIMIT alone
+ * (the reference does not evaluate collisions then).
+ *   is_feasible           == !(flags & (GH_FLAG_ENV  | GH_FLAG_LIMIT))
+ *   is_feasible_with_self == !(flags & (GH_FLAG_SELF | GH_FLAG_LIMIT)) */
+int gh_check_batch(gh_scene* scene, const void* q, size_t n, uint32_t what, uint8_t* flags);
+int gh_check_batch_dev(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
+                       uint8_t* flags_dev, void* hip_stream);
+
+/* Same, plus the first infeasible sample of each edge: the batched form of
+ * rrt's stop-at-first-failure stepping (joint_path_planner.rs:168-188).
+ * edge_off: [E+1] offsets into the n = edge_off[E] samples.
+ * first_bad[e]: index within edge e of the first sample with
+ * (flags & bad_mask) != 0, or -1. */
+int gh_check_edges(gh_scene* scene, const void* q, const uint32_t* edge_off, size_t n_edges,
+                   uint32_t what, uint8_t bad_mask, uint8_t* flags, int32_t* first_bad);
+int gh_check_edges_dev(gh_scene* scene, const void* q_dev, const uint32_t* edge_off_dev,
+                       size_t n_edges, size_t n_samples, uint32_t what, uint8_t bad_mask,
+                       uint8_t* flags_dev, int32_t* first_bad_dev, void* hip_stream);
+
+/* Replaces k::Chain::set_joint_positions + update_transforms as used at
+ * collision_checker.rs:54,124 and joint_path_planner.rs:245-247.
+ * poses: [n][N][7] = tx,ty,tz,qi,qj,qk,qw of every node's world transform.
+ * Limits are not checked here (set_joint_positions_unchecked semantics). */
+int gh_fk_batch(gh_scene* scene, const void* q, size_t n, void* poses);
+int gh_fk_batch_dev(gh_scene* scene, const void* q_dev, size_t n, void* poses_dev, void* hip_stream);
+
+/* Replaces colliding_link_names (joint_path_planner.rs:100-110), the
+ * non-early-exit diagnostic.  link_mask: [n][O][W] with W = gh_link_mask_words()
+ * 64-bit words; bit k of the mask for (config i, obstacle o) is set when node k
+ * would be yielded by check_env for obstacle o.  Decoding obstacle-major, then
+ * ascending node index, reproduces the reference's Vec<String> with its
+ * duplicates.  Limit violations yield all-zero masks. */
+int gh_link_hits(gh_scene* scene, const void* q, size_t n, uint64_t* link_mask);
+int gh_link_mask_words(const gh_scene* scene);
+
+/* Replaces colliding_link_names_with_self (joint_path_planner.rs:130-134).
+ * pair_mask: [n][ceil(P/64)] words; bit p set when self pair p is yielded. */
+int gh_self_hits(gh_scene* scene, const void* q, size_t n, uint64_t* pair_mask);
+
+/* Instrumented run (pairs culled / SAT'd / exact-tested; SURVEY.md 8d's s,g). */
+int gh_check_batch_counted(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
+                           uint8_t* flags_dev, gh_counters* out);
+
+const char* gh_last_error(void);
+const char* gh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEAR_HIP_H */

@@ -1,0 +1,959 @@
+// gear_oracle.hpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// A plain C++17 restatement of the algorithm on gear's planning hot path, used
+// solely as the checker in tests/, __graft_entry__.smoke() and as bench.py's
+// cpu_baseline leg.  Nothing under gear_amd/ may include, link or call it.
+//
+// What is restated, and from where (paths relative to /root/reference):
+//   - the loop structure of is_feasible / has_any_colliding /
+//     colliding_link_names / *_with_self   src/planner/joint_path_planner.rs:71-134
+//   - EnvCollisionNames / SelfCollisionPairs   src/collision/collision_checker.rs:48-101,115-200
+//   - URDF geometry -> shape                   src/collision/urdf.rs:10-73
+// The arithmetic lives in crates that are NOT vendored in the reference and not
+// on disk (Cargo.toml:17-28: k 0.20, ncollide3d 0.23, nalgebra 0.21; no
+// Cargo.lock).  Their published algorithms are restated here from memory:
+//   - k::Chain::set_joint_positions / update_transforms, k::urdf conversions
+//   - nalgebra Isometry3 / UnitQuaternion composition formulas
+//   - ncollide3d::query::distance dispatch, GJK (gjk::closest_points with
+//     VoronoiSimplex, eps_tol = 10*eps, eps_rel = sqrt(eps_tol)), point
+//     projection on segment / triangle / tetrahedron, composite-shape
+//     (TriMesh) distance = min over triangles with AABB pruning.
+// PINNING: the only known-answer test the reference holds on this path is
+// `collision_check` (joint_path_planner.rs:373-419, f32, margin 0.01): three
+// ordered link-name lists.  tests/test_oracle_golden.py checks this oracle
+// against them.  Numeric distances, GJK tolerances and f64 behaviour beyond
+// those lists are PARITY UNPINNED and are covered by analytic known answers
+// (tests/test_oracle_analytic.py).
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../include/gear_hip.h"
+
+namespace gear_oracle {
+
+// ---------------------------------------------------------------------------
+// nalgebra 0.21 restated: Vector3, UnitQuaternion, Isometry3
+// ---------------------------------------------------------------------------
+template <class T>
+struct V3 {
+  T x, y, z;
+  T& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+  T operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+template <class T> inline V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> inline V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> inline V3<T> operator-(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <class T> inline V3<T> operator*(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T> inline V3<T> operator/(V3<T> a, T s) { return {a.x / s, a.y / s, a.z / s}; }
+template <class T> inline T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> inline V3<T> cross(V3<T> a, V3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class T> inline T norm2(V3<T> a) { return dot(a, a); }
+template <class T> inline T norm(V3<T> a) { return std::sqrt(dot(a, a)); }
+
+template <class T>
+struct Quat {  // (i, j, k, w), unit
+  T i, j, k, w;
+};
+// nalgebra Quaternion * Quaternion (Hamilton product).
+template <class T> inline Quat<T> qmul(Quat<T> a, Quat<T> b) {
+  return {a.w * b.i + a.i * b.w + a.j * b.k - a.k * b.j,
+          a.w * b.j - a.i * b.k + a.j * b.w + a.k * b.i,
+          a.w * b.k + a.i * b.j - a.j * b.i + a.k * b.w,
+          a.w * b.w - a.i * b.i - a.j * b.j - a.k * b.k};
+}
+template <class T> inline Quat<T> qconj(Quat<T> a) { return {-a.i, -a.j, -a.k, a.w}; }
+// nalgebra UnitQuaternion * Vector3:  t = 2 (qv x v);  v + w t + qv x t
+template <class T> inline V3<T> qrot(Quat<T> q, V3<T> v) {
+  V3<T> qv{q.i, q.j, q.k};
+  V3<T> t = cross(qv, v) * T(2);
+  V3<T> c = cross(qv, t);
+  return t * q.w + c + v;
+}
+// UnitQuaternion::from_axis_angle(axis, angle)
+template <class T> inline Quat<T> q_axis_angle(V3<T> axis, T angle) {
+  T h = angle / T(2);
+  T s = std::sin(h), c = std::cos(h);
+  return {axis.x * s, axis.y * s, axis.z * s, c};
+}
+// UnitQuaternion::from_euler_angles(roll, pitch, yaw)
+template <class T> inline Quat<T> q_euler(T roll, T pitch, T yaw) {
+  T sr = std::sin(roll * T(0.5)), cr = std::cos(roll * T(0.5));
+  T sp = std::sin(pitch * T(0.5)), cp = std::cos(pitch * T(0.5));
+  T sy = std::sin(yaw * T(0.5)), cy = std::cos(yaw * T(0.5));
+  return {sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+          cr * cp * cy + sr * sp * sy};
+}
+
+template <class T>
+struct Iso {
+  V3<T> t;
+  Quat<T> r;
+  static Iso identity() { return {{0, 0, 0}, {0, 0, 0, 1}}; }
+};
+// Isometry * Isometry: (t1 + r1*t2, r1*r2)
+template <class T> inline Iso<T> imul(const Iso<T>& a, const Iso<T>& b) {
+  V3<T> shift = qrot(a.r, b.t);
+  return {a.t + shift, qmul(a.r, b.r)};
+}
+template <class T> inline Iso<T> iinv(const Iso<T>& a) {
+  Quat<T> r = qconj(a.r);
+  return {qrot(r, -a.t), r};
+}
+template <class T> inline V3<T> ipoint(const Iso<T>& m, V3<T> p) { return qrot(m.r, p) + m.t; }
+template <class T> inline V3<T> ivec(const Iso<T>& m, V3<T> v) { return qrot(m.r, v); }
+template <class T> inline V3<T> iinvvec(const Iso<T>& m, V3<T> v) { return qrot(qconj(m.r), v); }
+
+// ---------------------------------------------------------------------------
+// ncollide3d 0.23 shapes restated
+// ---------------------------------------------------------------------------
+enum ShapeKind { K_BOX = 0, K_BALL = 1, K_TRI = 2, K_MESH = 3 };
+
+template <class T>
+struct AABB {
+  V3<T> lo, hi;
+};
+
+template <class T>
+struct BvhNode {
+  AABB<T> bb;
+  int left, right;  // children, -1 for leaf
+  int tri;          // leaf: triangle index
+};
+
+template <class T>
+struct Shape {
+  int kind = K_BOX;
+  V3<T> half{0, 0, 0};        // Cuboid half extents
+  T radius = 0;               // Ball
+  V3<T> a{}, b{}, c{};        // Triangle
+  std::vector<V3<T>> verts;   // TriMesh
+  std::vector<std::array<int, 3>> tris;
+  std::vector<BvhNode<T>> bvh;  // root = 0
+};
+
+// SupportMap::local_support_point (Cuboid: copysign; Ball: dir*r; Triangle: max dot)
+template <class T> inline V3<T> local_support(const Shape<T>& s, V3<T> d) {
+  switch (s.kind) {
+    case K_BOX:
+      return {std::copysign(s.half.x, d.x), std::copysign(s.half.y, d.y), std::copysign(s.half.z, d.z)};
+    case K_BALL:
+      return d * s.radius;
+    default: {  // triangle
+      T d1 = dot(s.a, d), d2 = dot(s.b, d), d3 = dot(s.c, d);
+      if (d1 > d2) return d1 > d3 ? s.a : s.c;
+      return d2 > d3 ? s.b : s.c;
+    }
+  }
+}
+// SupportMap::support_point_toward(m, dir)
+template <class T> inline V3<T> support_toward(const Shape<T>& s, const Iso<T>& m, V3<T> dir) {
+  V3<T> ld = iinvvec(m, dir);
+  return ipoint(m, local_support(s, ld));
+}
+
+template <class T>
+struct CSOPoint {
+  V3<T> point, orig1, orig2;
+};
+template <class T>
+inline CSOPoint<T> cso_from_shapes(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2,
+                                   const Shape<T>& g2, V3<T> dir) {
+  V3<T> sp1 = support_toward(g1, m1, dir);
+  V3<T> sp2 = support_toward(g2, m2, -dir);
+  return {sp1 - sp2, sp1, sp2};
+}
+
+// ---------------------------------------------------------------------------
+// point projection with location: Segment, Triangle, Tetrahedron (origin query)
+// ---------------------------------------------------------------------------
+enum LocKind { ON_VERTEX, ON_EDGE, ON_FACE, ON_SOLID };
+template <class T>
+struct Loc {
+  LocKind kind;
+  int id;
+  T bc[3];
+};
+
+template <class T> inline V3<T> project_segment(V3<T> a, V3<T> b, V3<T> pt, Loc<T>& loc) {
+  V3<T> ab = b - a, ap = pt - a;
+  T ab_ap = dot(ab, ap), sqnab = norm2(ab);
+  if (ab_ap <= T(0)) { loc = {ON_VERTEX, 0, {1, 0, 0}}; return a; }
+  if (ab_ap >= sqnab) { loc = {ON_VERTEX, 1, {1, 0, 0}}; return b; }
+  T u = ab_ap / sqnab;
+  loc = {ON_EDGE, 0, {T(1) - u, u, 0}};
+  return a + ab * u;
+}
+
+template <class T>
+inline V3<T> project_triangle(V3<T> a, V3<T> b, V3<T> c, V3<T> pt, Loc<T>& loc) {
+  V3<T> ab = b - a, ac = c - a, ap = pt - a;
+  T ab_ap = dot(ab, ap), ac_ap = dot(ac, ap);
+  if (ab_ap <= T(0) && ac_ap <= T(0)) { loc = {ON_VERTEX, 0, {1, 0, 0}}; return a; }
+  V3<T> bp = pt - b;
+  T ab_bp = dot(ab, bp), ac_bp = dot(ac, bp);
+  if (ab_bp >= T(0) && ac_bp <= ab_bp) { loc = {ON_VERTEX, 1, {1, 0, 0}}; return b; }
+  V3<T> cp = pt - c;
+  T ab_cp = dot(ab, cp), ac_cp = dot(ac, cp);
+  if (ac_cp >= T(0) && ab_cp <= ac_cp) { loc = {ON_VERTEX, 2, {1, 0, 0}}; return c; }
+  V3<T> bc = c - b;
+  // stable edge-region checks via explicit cross products
+  V3<T> n = cross(ab, ac);
+  T vc = dot(n, cross(ab, ap));
+  if (vc < T(0) && ab_ap >= T(0) && ab_bp <= T(0)) {
+    T v = ab_ap / norm2(ab);
+    loc = {ON_EDGE, 0, {T(1) - v, v, 0}};
+    return a + ab * v;
+  }
+  T vb = -dot(n, cross(ac, cp));
+  if (vb < T(0) && ac_ap >= T(0) && ac_cp <= T(0)) {
+    T w = ac_ap / norm2(ac);
+    loc = {ON_EDGE, 2, {T(1) - w, w, 0}};
+    return a + ac * w;
+  }
+  T va = dot(n, cross(bc, bp));
+  if (va < T(0) && ac_bp - ab_bp >= T(0) && ab_cp - ac_cp >= T(0)) {
+    T w = dot(bc, bp) / norm2(bc);
+    loc = {ON_EDGE, 1, {T(1) - w, w, 0}};
+    return b + bc * w;
+  }
+  T denom = T(1) / (va + vb + vc);
+  T v = vb * denom, w = vc * denom;
+  loc = {ON_FACE, 0, {T(1) - v - w, v, w}};
+  return a + ab * v + ac * w;
+}
+
+template <class T>
+inline bool tet_check_edge(int id, V3<T> a, V3<T> ab, V3<T> nabc, V3<T> nabd, V3<T> ap, T ap_ab,
+                           T bp_ab, T& dabc, T& dabd, V3<T>& proj, Loc<T>& loc) {
+  T ab_ab = ap_ab - bp_ab;
+  V3<T> ap_x_ab = cross(ap, ab);
+  dabc = dot(ap_x_ab, nabc);
+  dabd = dot(ap_x_ab, nabd);
+  if (ab_ab != T(0) && dabc >= T(0) && dabd >= T(0) && ap_ab >= T(0) && ap_ab <= ab_ab) {
+    T u = ap_ab / ab_ab;
+    loc = {ON_EDGE, id, {T(1) - u, u, 0}};
+    proj = a + ab * u;
+    return true;
+  }
+  return false;
+}
+template <class T>
+inline bool tet_check_face(int id, V3<T> a, V3<T> b, V3<T> c, V3<T> ap, V3<T> bp, V3<T> cp,
+                           V3<T> ab, V3<T> ac, V3<T> ad, T d1, T d2, T d3, V3<T>& proj,
+                           Loc<T>& loc) {
+  if (d1 < T(0) && d2 < T(0) && d3 < T(0)) {
+    V3<T> n = cross(ab, ac);
+    if (dot(n, ad) * dot(n, ap) < T(0)) {
+      T nn = norm(n);
+      if (nn > std::numeric_limits<T>::epsilon()) {
+        V3<T> normal = n / nn;
+        T vc = dot(normal, cross(ab, ap));
+        T va = dot(normal, cross(bp, cp));
+        T vb = dot(normal, cross(cp, ap));
+        T inv = T(1) / (va + vb + vc);
+        loc = {ON_FACE, id, {va * inv, vb * inv, vc * inv}};
+        proj = a * loc.bc[0] + b * loc.bc[1] + c * loc.bc[2];
+        return true;
+      }
+    }
+  }
+  return false;
+}
+
+template <class T>
+inline V3<T> project_tetra(V3<T> a, V3<T> b, V3<T> c, V3<T> d, V3<T> pt, Loc<T>& loc) {
+  V3<T> ab = b - a, ac = c - a, ad = d - a, ap = pt - a;
+  T ap_ab = dot(ap, ab), ap_ac = dot(ap, ac), ap_ad = dot(ap, ad);
+  if (ap_ab <= T(0) && ap_ac <= T(0) && ap_ad <= T(0)) { loc = {ON_VERTEX, 0, {1, 0, 0}}; return a; }
+  V3<T> bc = c - b, bd = d - b, bp = pt - b;
+  T bp_bc = dot(bp, bc), bp_bd = dot(bp, bd), bp_ab = dot(bp, ab);
+  if (bp_bc <= T(0) && bp_bd <= T(0) && bp_ab >= T(0)) { loc = {ON_VERTEX, 1, {1, 0, 0}}; return b; }
+  V3<T> cd = d - c, cp = pt - c;
+  T cp_ac = dot(cp, ac), cp_bc = dot(cp, bc), cp_cd = dot(cp, cd);
+  if (cp_cd <= T(0) && cp_bc >= T(0) && cp_ac >= T(0)) { loc = {ON_VERTEX, 2, {1, 0, 0}}; return c; }
+  V3<T> dp = pt - d;
+  T dp_cd = dot(dp, cd), dp_bd = dot(dp, bd), dp_ad = dot(dp, ad);
+  if (dp_ad >= T(0) && dp_bd >= T(0) && dp_cd >= T(0)) { loc = {ON_VERTEX, 3, {1, 0, 0}}; return d; }
+
+  V3<T> proj{};
+  V3<T> nabc = cross(ab, ac), nabd = cross(ab, ad);
+  T dabc, dabd;
+  if (tet_check_edge(0, a, ab, nabc, nabd, ap, ap_ab, bp_ab, dabc, dabd, proj, loc)) return proj;
+  V3<T> nacd = cross(ac, ad);
+  T dacd, dacb;
+  if (tet_check_edge(1, a, ac, nacd, -nabc, ap, ap_ac, cp_ac, dacd, dacb, proj, loc)) return proj;
+  T dadb, dadc;
+  if (tet_check_edge(2, a, ad, -nabd, -nacd, ap, ap_ad, dp_ad, dadb, dadc, proj, loc)) return proj;
+  V3<T> nbcd = cross(bc, bd);
+  T dbca, dbcd;
+  if (tet_check_edge(3, b, bc, nabc, nbcd, bp, bp_bc, cp_bc, dbca, dbcd, proj, loc)) return proj;
+  T dbdc, dbda;
+  if (tet_check_edge(4, b, bd, -nbcd, nabd, bp, bp_bd, dp_bd, dbdc, dbda, proj, loc)) return proj;
+  T dcda, dcdb;
+  if (tet_check_edge(5, c, cd, nacd, nbcd, cp, cp_cd, dp_cd, dcda, dcdb, proj, loc)) return proj;
+
+  if (tet_check_face(0, a, b, c, ap, bp, cp, ab, ac, ad, dabc, dbca, dacb, proj, loc)) return proj;
+  if (tet_check_face(1, a, b, d, ap, bp, dp, ab, ad, ac, dadb, dabd, dbda, proj, loc)) return proj;
+  if (tet_check_face(2, a, c, d, ap, cp, dp, ac, ad, ab, dacd, dcda, dadc, proj, loc)) return proj;
+  if (tet_check_face(3, b, c, d, bp, cp, dp, bc, bd, -ab, dbcd, dcdb, dbdc, proj, loc)) return proj;
+  loc = {ON_SOLID, 0, {0, 0, 0}};
+  return pt;
+}
+
+// ---------------------------------------------------------------------------
+// VoronoiSimplex (3D) + gjk::closest_points
+// ---------------------------------------------------------------------------
+template <class T> inline T eps_tol() { return std::numeric_limits<T>::epsilon() * T(10); }
+
+template <class T>
+struct VoronoiSimplex {
+  CSOPoint<T> v[4];
+  T proj[3] = {0, 0, 0};
+  int dim = 0;
+  // snapshot of the simplex before the last add_point (for result(prev = true))
+  CSOPoint<T> pv[4];
+  T pproj[3] = {0, 0, 0};
+  int pdim = 0;
+
+  void reset(const CSOPoint<T>& p) { dim = 0; pdim = 0; v[0] = p; }
+  void swap(int i, int j) { std::swap(v[i], v[j]); }
+
+  bool add_point(const CSOPoint<T>& pt) {
+    pdim = dim;
+    for (int i = 0; i < 3; i++) pproj[i] = proj[i];
+    for (int i = 0; i <= dim; i++) pv[i] = v[i];
+    const T tol = eps_tol<T>();
+    switch (dim) {
+      case 0:
+        if (norm2(v[0].point - pt.point) < tol) return false;
+        break;
+      case 1: {
+        V3<T> ab = v[1].point - v[0].point, ac = pt.point - v[0].point;
+        if (norm2(cross(ab, ac)) < tol) return false;
+        break;
+      }
+      case 2: {
+        V3<T> ab = v[1].point - v[0].point, ac = v[2].point - v[0].point, ap = pt.point - v[0].point;
+        V3<T> n = cross(ab, ac);
+        n = n / norm(n);
+        if (std::abs(dot(n, ap)) < tol) return false;
+        break;
+      }
+      default:
+        return false;
+    }
+    dim += 1;
+    v[dim] = pt;
+    return true;
+  }
+
+  V3<T> project_origin_and_reduce() {
+    const V3<T> o{0, 0, 0};
+    Loc<T> loc;
+    if (dim == 0) {
+      proj[0] = 1;
+      return v[0].point;
+    } else if (dim == 1) {
+      V3<T> p = project_segment(v[0].point, v[1].point, o, loc);
+      if (loc.kind == ON_VERTEX) {
+        if (loc.id == 1) swap(0, 1);
+        proj[0] = 1;
+        dim = 0;
+      } else {
+        proj[0] = loc.bc[0];
+        proj[1] = loc.bc[1];
+      }
+      return p;
+    } else if (dim == 2) {
+      V3<T> p = project_triangle(v[0].point, v[1].point, v[2].point, o, loc);
+      if (loc.kind == ON_VERTEX) {
+        swap(0, loc.id);
+        proj[0] = 1;
+        dim = 0;
+      } else if (loc.kind == ON_EDGE) {
+        if (loc.id == 0) { proj[0] = loc.bc[0]; proj[1] = loc.bc[1]; }
+        else if (loc.id == 1) { swap(0, 2); proj[0] = loc.bc[1]; proj[1] = loc.bc[0]; }
+        else { swap(1, 2); proj[0] = loc.bc[0]; proj[1] = loc.bc[1]; }
+        dim = 1;
+      } else {
+        proj[0] = loc.bc[0]; proj[1] = loc.bc[1]; proj[2] = loc.bc[2];
+      }
+      return p;
+    } else {
+      V3<T> p = project_tetra(v[0].point, v[1].point, v[2].point, v[3].point, o, loc);
+      if (loc.kind == ON_VERTEX) {
+        swap(0, loc.id);
+        proj[0] = 1;
+        dim = 0;
+      } else if (loc.kind == ON_EDGE) {
+        switch (loc.id) {
+          case 0: break;
+          case 1: swap(1, 2); break;
+          case 2: swap(1, 3); break;
+          case 3: swap(0, 2); break;
+          case 4: swap(0, 3); break;
+          default: swap(0, 2); swap(1, 3); break;
+        }
+        if (loc.id == 3 || loc.id == 4) { proj[0] = loc.bc[1]; proj[1] = loc.bc[0]; }
+        else { proj[0] = loc.bc[0]; proj[1] = loc.bc[1]; }
+        dim = 1;
+      } else if (loc.kind == ON_FACE) {
+        CSOPoint<T> a = v[0], b = v[1], c = v[2], d = v[3];
+        switch (loc.id) {
+          case 0: break;
+          case 1: v[0] = a; v[1] = b; v[2] = d; v[3] = c; break;
+          case 2: v[0] = a; v[1] = c; v[2] = d; v[3] = b; break;
+          default: v[0] = b; v[1] = c; v[2] = d; v[3] = a; break;
+        }
+        proj[0] = loc.bc[0]; proj[1] = loc.bc[1]; proj[2] = loc.bc[2];
+        dim = 2;
+      }
+      return p;
+    }
+  }
+};
+
+enum GjkKind { GJK_INTERSECTION, GJK_CLOSEST, GJK_NO_INTERSECTION };
+template <class T>
+struct GjkResult {
+  GjkKind kind;
+  V3<T> p1, p2;
+  int iters;
+};
+
+template <class T>
+inline void gjk_witness(const VoronoiSimplex<T>& s, bool prev, V3<T>& p1, V3<T>& p2) {
+  p1 = {0, 0, 0};
+  p2 = {0, 0, 0};
+  if (prev) {
+    for (int i = 0; i <= s.pdim; i++) {
+      p1 = p1 + s.pv[i].orig1 * s.pproj[i];
+      p2 = p2 + s.pv[i].orig2 * s.pproj[i];
+    }
+  } else {
+    for (int i = 0; i <= s.dim; i++) {
+      p1 = p1 + s.v[i].orig1 * s.proj[i];
+      p2 = p2 + s.v[i].orig2 * s.proj[i];
+    }
+  }
+}
+
+// gjk::closest_points(m1, g1, m2, g2, max_dist = MAX, exact_dist = true, simplex)
+template <class T>
+inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2,
+                                       const Shape<T>& g2, VoronoiSimplex<T>& simplex) {
+  const T tol = eps_tol<T>();
+  const T rel = std::sqrt(tol);
+  GjkResult<T> res{GJK_INTERSECTION, {0, 0, 0}, {0, 0, 0}, 0};
+  V3<T> proj = simplex.project_origin_and_reduce();
+  T n2 = norm2(proj);
+  if (!(n2 > T(0))) return res;
+  V3<T> old_dir = -(proj / std::sqrt(n2));
+  T max_bound = std::numeric_limits<T>::max();
+  V3<T> dir{};
+  int niter = 0;
+  for (;;) {
+    T old_max_bound = max_bound;
+    T sq = norm2(proj);
+    if (sq > tol * tol) {
+      T n = std::sqrt(sq);
+      dir = -(proj / n);
+      max_bound = n;
+    } else {
+      res.kind = GJK_INTERSECTION;
+      res.iters = niter;
+      return res;
+    }
+    if (max_bound >= old_max_bound) {
+      res.kind = GJK_CLOSEST;
+      gjk_witness(simplex, true, res.p1, res.p2);
+      res.iters = niter;
+      return res;
+    }
+    CSOPoint<T> cso = cso_from_shapes(m1, g1, m2, g2, dir);
+    T min_bound = -dot(dir, cso.point);
+    if (max_bound - min_bound <= rel * max_bound) {
+      res.kind = GJK_CLOSEST;
+      gjk_witness(simplex, false, res.p1, res.p2);
+      res.iters = niter;
+      return res;
+    }
+    if (!simplex.add_point(cso)) {
+      res.kind = GJK_CLOSEST;
+      gjk_witness(simplex, false, res.p1, res.p2);
+      res.iters = niter;
+      return res;
+    }
+    old_dir = dir;
+    proj = simplex.project_origin_and_reduce();
+    if (simplex.dim == 3) {
+      if (min_bound >= tol) {
+        res.kind = GJK_CLOSEST;
+        gjk_witness(simplex, true, res.p1, res.p2);
+      } else {
+        res.kind = GJK_INTERSECTION;
+      }
+      res.iters = niter;
+      return res;
+    }
+    niter += 1;
+    if (niter == 10000) {
+      res.kind = GJK_NO_INTERSECTION;
+      res.iters = niter;
+      return res;
+    }
+  }
+}
+
+struct Stats {
+  uint64_t gjk_calls = 0, gjk_iters = 0, pair_tests = 0;
+};
+
+// distance_support_map_support_map
+template <class T>
+inline T distance_support_maps(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2,
+                               const Shape<T>& g2, Stats* st = nullptr) {
+  V3<T> dir = m1.t - m2.t;
+  T n2 = norm2(dir);
+  T e = std::numeric_limits<T>::epsilon();
+  VoronoiSimplex<T> simplex;
+  if (n2 > e * e) dir = dir / std::sqrt(n2);
+  else dir = {1, 0, 0};
+  simplex.reset(cso_from_shapes(m1, g1, m2, g2, dir));
+  GjkResult<T> r = gjk_closest_points(m1, g1, m2, g2, simplex);
+  if (st) { st->gjk_calls++; st->gjk_iters += (uint64_t)r.iters + 1; }
+  if (r.kind == GJK_CLOSEST) return norm(r.p1 - r.p2);
+  return T(0);  // Intersection, or "GJK did not converge"
+}
+
+// ---- AABBs ----------------------------------------------------------------
+template <class T> inline AABB<T> aabb_of(const Shape<T>& g, const Iso<T>& m) {
+  switch (g.kind) {
+    case K_BOX: {
+      // absolute_transform_vector: |R| * half
+      V3<T> ex = ivec(m, V3<T>{1, 0, 0}), ey = ivec(m, V3<T>{0, 1, 0}), ez = ivec(m, V3<T>{0, 0, 1});
+      V3<T> h{std::abs(ex.x) * g.half.x + std::abs(ey.x) * g.half.y + std::abs(ez.x) * g.half.z,
+              std::abs(ex.y) * g.half.x + std::abs(ey.y) * g.half.y + std::abs(ez.y) * g.half.z,
+              std::abs(ex.z) * g.half.x + std::abs(ey.z) * g.half.y + std::abs(ez.z) * g.half.z};
+      return {m.t - h, m.t + h};
+    }
+    case K_BALL: {
+      V3<T> h{g.radius, g.radius, g.radius};
+      return {m.t - h, m.t + h};
+    }
+    case K_TRI: {
+      V3<T> a = ipoint(m, g.a), b = ipoint(m, g.b), c = ipoint(m, g.c);
+      return {{std::min({a.x, b.x, c.x}), std::min({a.y, b.y, c.y}), std::min({a.z, b.z, c.z})},
+              {std::max({a.x, b.x, c.x}), std::max({a.y, b.y, c.y}), std::max({a.z, b.z, c.z})}};
+    }
+    default: {  // mesh: transform the root AABB (center / |R| half extents)
+      const AABB<T>& r = g.bvh[0].bb;
+      V3<T> cl = (r.lo + r.hi) * T(0.5), hl = (r.hi - r.lo) * T(0.5);
+      V3<T> c = ipoint(m, cl);
+      V3<T> ex = ivec(m, V3<T>{1, 0, 0}), ey = ivec(m, V3<T>{0, 1, 0}), ez = ivec(m, V3<T>{0, 0, 1});
+      V3<T> h{std::abs(ex.x) * hl.x + std::abs(ey.x) * hl.y + std::abs(ez.x) * hl.z,
+              std::abs(ex.y) * hl.x + std::abs(ey.y) * hl.y + std::abs(ez.y) * hl.z,
+              std::abs(ex.z) * hl.x + std::abs(ey.z) * hl.y + std::abs(ez.z) * hl.z};
+      return {c - h, c + h};
+    }
+  }
+}
+
+template <class T> inline void build_bvh(Shape<T>& mesh) {
+  // Median split over triangle centroids; the tree only prunes, it never
+  // changes the minimum (see distance_composite below).
+  int nt = (int)mesh.tris.size();
+  std::vector<int> order(nt);
+  std::vector<AABB<T>> tb(nt);
+  std::vector<V3<T>> cen(nt);
+  for (int i = 0; i < nt; i++) {
+    order[i] = i;
+    V3<T> a = mesh.verts[mesh.tris[i][0]], b = mesh.verts[mesh.tris[i][1]], c = mesh.verts[mesh.tris[i][2]];
+    tb[i] = {{std::min({a.x, b.x, c.x}), std::min({a.y, b.y, c.y}), std::min({a.z, b.z, c.z})},
+             {std::max({a.x, b.x, c.x}), std::max({a.y, b.y, c.y}), std::max({a.z, b.z, c.z})}};
+    cen[i] = (a + b + c) * T(1.0 / 3.0);
+  }
+  mesh.bvh.clear();
+  struct Rec {
+    static int build(Shape<T>& m, std::vector<int>& ord, int lo, int hi, const std::vector<AABB<T>>& tb,
+                     const std::vector<V3<T>>& cen) {
+      int id = (int)m.bvh.size();
+      m.bvh.push_back({});
+      AABB<T> bb = tb[ord[lo]];
+      for (int i = lo + 1; i < hi; i++) {
+        const AABB<T>& o = tb[ord[i]];
+        bb.lo = {std::min(bb.lo.x, o.lo.x), std::min(bb.lo.y, o.lo.y), std::min(bb.lo.z, o.lo.z)};
+        bb.hi = {std::max(bb.hi.x, o.hi.x), std::max(bb.hi.y, o.hi.y), std::max(bb.hi.z, o.hi.z)};
+      }
+      if (hi - lo == 1) {
+        m.bvh[id] = {bb, -1, -1, ord[lo]};
+        return id;
+      }
+      V3<T> e = bb.hi - bb.lo;
+      int ax = (e.x >= e.y && e.x >= e.z) ? 0 : (e.y >= e.z ? 1 : 2);
+      int mid = (lo + hi) / 2;
+      std::nth_element(ord.begin() + lo, ord.begin() + mid, ord.begin() + hi,
+                       [&](int p, int q) { return cen[p][ax] < cen[q][ax]; });
+      int l = build(m, ord, lo, mid, tb, cen);
+      int r = build(m, ord, mid, hi, tb, cen);
+      m.bvh[id] = {bb, l, r, -1};
+      return id;
+    }
+  };
+  if (nt > 0) Rec::build(mesh, order, 0, nt, tb, cen);
+}
+
+template <class T> inline T aabb_msum_dist(const AABB<T>& bv, V3<T> shift, V3<T> margin) {
+  V3<T> lo = bv.lo + shift + (-margin), hi = bv.hi + shift + margin;
+  T dx = std::max({lo.x, -hi.x, T(0)}), dy = std::max({lo.y, -hi.y, T(0)}), dz = std::max({lo.z, -hi.z, T(0)});
+  return std::sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+template <class T>
+T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2, Stats* st);
+
+// distance_composite_shape_shape(m1, mesh g1, m2, g2): min over triangles of g1
+template <class T>
+inline T distance_composite(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2,
+                            bool swapped, Stats* st) {
+  Iso<T> ls_m2 = imul(iinv(m1), m2);
+  AABB<T> bb2 = aabb_of(g2, ls_m2);
+  V3<T> shift = -((bb2.lo + bb2.hi) * T(0.5));
+  V3<T> marg = (bb2.hi - bb2.lo) * T(0.5);
+  T best = std::numeric_limits<T>::max();
+  int stack[128];
+  int sp = 0;
+  stack[sp++] = 0;
+  Shape<T> tri;
+  tri.kind = K_TRI;
+  while (sp > 0) {
+    int id = stack[--sp];
+    const BvhNode<T>& nd = g1.bvh[id];
+    T lb = aabb_msum_dist(nd.bb, shift, marg);
+    if (!(lb < best)) continue;
+    if (nd.left < 0) {
+      const auto& t = g1.tris[nd.tri];
+      tri.a = g1.verts[t[0]];
+      tri.b = g1.verts[t[1]];
+      tri.c = g1.verts[t[2]];
+      // map_part_at hands (m1, triangle); argument order follows the caller's
+      T d = swapped ? distance(m2, g2, m1, tri, st) : distance(m1, tri, m2, g2, st);
+      if (d < best) best = d;
+    } else {
+      T ll = aabb_msum_dist(g1.bvh[nd.left].bb, shift, marg);
+      T lr = aabb_msum_dist(g1.bvh[nd.right].bb, shift, marg);
+      // visit the nearer child first
+      if (ll <= lr) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+      else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
+    }
+  }
+  return best;
+}
+
+// ncollide3d::query::distance dispatch
+template <class T>
+T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2, Stats* st) {
+  if (g1.kind == K_BALL && g2.kind == K_BALL) {
+    // distance_ball_ball
+    T d2 = norm2(m1.t - m2.t);
+    T sum = g1.radius + g2.radius;
+    if (d2 <= sum * sum) return T(0);
+    return std::sqrt(d2) - sum;
+  }
+  if (g1.kind != K_MESH && g2.kind != K_MESH) return distance_support_maps(m1, g1, m2, g2, st);
+  if (g1.kind == K_MESH) return distance_composite(m1, g1, m2, g2, false, st);
+  return distance_composite(m2, g2, m1, g1, true, st);
+}
+
+// ---------------------------------------------------------------------------
+// urdf_geometry_to_shape_handle (src/collision/urdf.rs:10-73)
+// ---------------------------------------------------------------------------
+template <class T> inline Shape<T> make_box(double hx, double hy, double hz) {
+  Shape<T> s;
+  s.kind = K_BOX;
+  s.half = {T(hx), T(hy), T(hz)};  // na::convert(size * 0.5): f64 product, then cast
+  return s;
+}
+template <class T> inline Shape<T> make_ball(double r) {
+  Shape<T> s;
+  s.kind = K_BALL;
+  s.radius = T(r);
+  return s;
+}
+// Cylinder::new(convert(length*0.5), convert(radius)).to_trimesh(30), xzy swizzle,
+// convex_hull -> TriMesh.  The hull of the 60 points is the 30-gon prism; its
+// surface (hence the distance) does not depend on the triangulation chosen.
+template <class T> inline Shape<T> make_cylinder(double radius, double length) {
+  Shape<T> s;
+  s.kind = K_MESH;
+  const int n = 30;
+  T half_height = T(length * 0.5), r = T(radius);
+  T diameter = r * T(2), height = half_height * T(2);
+  T two_pi = T(6.283185307179586476925286766559);
+  T dtheta = two_pi * (T(1) / T(n));
+  for (int cap = 0; cap < 2; cap++) {
+    T y = cap == 0 ? T(-0.5) : T(0.5);
+    T th = 0;
+    for (int i = 0; i < n; i++) {
+      T px = std::cos(th) * T(0.5), pz = std::sin(th) * T(0.5);
+      // scale_by(diameter, height, diameter), then xzy
+      s.verts.push_back({px * diameter, pz * diameter, y * height});
+      th = th + dtheta;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    int j = (i + 1) % n;
+    s.tris.push_back({i, j, n + i});
+    s.tris.push_back({j, n + j, n + i});
+  }
+  for (int i = 1; i + 1 < n; i++) {
+    s.tris.push_back({0, i + 1, i});
+    s.tris.push_back({n, n + i, n + i + 1});
+  }
+  build_bvh(s);
+  return s;
+}
+template <class T> inline Shape<T> make_mesh(const gh_mesh_desc& m) {
+  Shape<T> s;
+  s.kind = K_MESH;
+  for (int i = 0; i < m.n_vertices; i++)
+    s.verts.push_back({T(m.vertices[3 * i]), T(m.vertices[3 * i + 1]), T(m.vertices[3 * i + 2])});
+  for (int i = 0; i < m.n_triangles; i++)
+    s.tris.push_back({m.triangles[3 * i], m.triangles[3 * i + 1], m.triangles[3 * i + 2]});
+  build_bvh(s);
+  return s;
+}
+template <class T> inline Shape<T> make_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes) {
+  switch (d.kind) {
+    case GH_SHAPE_BOX: return make_box<T>(d.params[0], d.params[1], d.params[2]);
+    case GH_SHAPE_BALL: return make_ball<T>(d.params[0]);
+    case GH_SHAPE_CYLINDER: return make_cylinder<T>(d.params[0], d.params[1]);
+    default: return make_mesh<T>(meshes[d.mesh]);
+  }
+}
+template <class T> inline Iso<T> make_iso(const double* t, const double* q) {
+  return {{T(t[0]), T(t[1]), T(t[2])}, {T(q[0]), T(q[1]), T(q[2]), T(q[3])}};
+}
+
+// ---------------------------------------------------------------------------
+// k 0.20 restated: Chain, set_joint_positions, update_transforms
+// ---------------------------------------------------------------------------
+template <class T>
+struct Node {
+  int parent;
+  int joint_type;
+  V3<T> axis;
+  Iso<T> origin;
+  bool has_limit;
+  T lo, hi;
+  int mimic_parent;
+  T mimic_mult, mimic_off;
+  T position;
+  std::vector<int> mimic_children;
+};
+
+template <class T>
+struct LinkShape {
+  Shape<T> shape;
+  Iso<T> local;
+};
+template <class T>
+struct Obstacle {
+  Shape<T> shape;
+  Iso<T> pose;
+};
+
+template <class T>
+struct Scene {
+  std::vector<Node<T>> nodes;
+  std::vector<int> col_node;
+  std::vector<std::vector<LinkShape<T>>> link_shapes;  // name_collision_model_map, keyed by node
+  std::vector<Obstacle<T>> obstacles;                  // Compound::shapes()
+  std::vector<std::array<int, 2>> pairs;
+  T margin;  // CollisionChecker::prediction
+
+  Scene(const gh_robot_desc& r, const gh_obstacle_desc& o, double m) : margin(T(m)) {
+    nodes.resize(r.n_nodes);
+    for (int i = 0; i < r.n_nodes; i++) {
+      const gh_node_desc& d = r.nodes[i];
+      Node<T>& n = nodes[i];
+      n.parent = d.parent;
+      n.joint_type = d.joint_type;
+      // k::urdf::axis_from: convert to T, then Unit::new_normalize in T
+      V3<T> ax{T(d.axis[0]), T(d.axis[1]), T(d.axis[2])};
+      T an = norm(ax);
+      n.axis = an > T(0) ? ax / an : ax;
+      n.origin = make_iso<T>(d.origin_t, d.origin_q);
+      n.has_limit = d.has_limit != 0;
+      n.lo = T(d.limit_lo);
+      n.hi = T(d.limit_hi);
+      n.mimic_parent = d.mimic_parent;
+      n.mimic_mult = T(d.mimic_mult);
+      n.mimic_off = T(d.mimic_offset);
+      n.position = T(d.position);
+    }
+    for (int i = 0; i < r.n_nodes; i++)
+      if (nodes[i].mimic_parent >= 0) nodes[nodes[i].mimic_parent].mimic_children.push_back(i);
+    col_node.assign(r.col_node, r.col_node + r.n_cols);
+    link_shapes.resize(r.n_nodes);
+    for (int i = 0; i < r.n_shapes; i++) {
+      const gh_shape_desc& d = r.shapes[i];
+      link_shapes[d.node].push_back({make_shape<T>(d, r.meshes), make_iso<T>(d.t, d.q)});
+    }
+    for (int i = 0; i < o.n_shapes; i++) {
+      const gh_shape_desc& d = o.shapes[i];
+      obstacles.push_back({make_shape<T>(d, o.meshes), make_iso<T>(d.t, d.q)});
+    }
+    for (int i = 0; i < r.n_pairs; i++) pairs.push_back({r.pairs[2 * i], r.pairs[2 * i + 1]});
+  }
+
+  int dof() const { return (int)col_node.size(); }
+
+  void initial_positions(std::vector<T>& pos) const {
+    pos.resize(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) pos[i] = nodes[i].position;
+  }
+
+  // k::Chain::set_joint_positions: per movable joint of `using_joints`, in
+  // order: mimic joints ignore their own input; Range::is_valid = lo<=v<=hi;
+  // mimic children get offset + mult*v through the same limit check.
+  // Returns false on OutOfLimitError (joints set so far stay set).
+  bool set_joint_positions(const T* q, std::vector<T>& pos) const {
+    for (size_t c = 0; c < col_node.size(); c++) {
+      int ni = col_node[c];
+      const Node<T>& n = nodes[ni];
+      if (n.mimic_parent >= 0) continue;
+      T v = q[c];
+      if (n.has_limit && !(v <= n.hi && v >= n.lo)) return false;
+      pos[ni] = v;
+      for (int ch : n.mimic_children) {
+        const Node<T>& cn = nodes[ch];
+        T cv = cn.mimic_off + cn.mimic_mult * v;
+        if (cn.has_limit && !(cv <= cn.hi && cv >= cn.lo)) return false;
+        pos[ch] = cv;
+      }
+    }
+    return true;
+  }
+  // set_joint_positions_unchecked
+  void set_joint_positions_unchecked(const T* q, std::vector<T>& pos) const {
+    for (size_t c = 0; c < col_node.size(); c++) {
+      int ni = col_node[c];
+      const Node<T>& n = nodes[ni];
+      if (n.mimic_parent >= 0) continue;
+      pos[ni] = q[c];
+      for (int ch : n.mimic_children) pos[ch] = nodes[ch].mimic_off + nodes[ch].mimic_mult * q[c];
+    }
+  }
+
+  // Joint::local_transform: origin * joint_transform
+  Iso<T> local_transform(const Node<T>& n, T position) const {
+    Iso<T> jt = Iso<T>::identity();
+    if (n.joint_type == GH_JOINT_ROTATIONAL) jt.r = q_axis_angle(n.axis, position);
+    else if (n.joint_type == GH_JOINT_LINEAR) jt.t = n.axis * position;
+    return imul(n.origin, jt);
+  }
+  // Chain::update_transforms: world = parent_world * local, DFS order
+  void update_transforms(const std::vector<T>& pos, std::vector<Iso<T>>& world) const {
+    world.resize(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+      Iso<T> pw = nodes[i].parent >= 0 ? world[nodes[i].parent] : Iso<T>::identity();
+      world[i] = imul(pw, local_transform(nodes[i], pos[i]));
+    }
+  }
+
+  // EnvCollisionNames for one obstacle: node-index list in DFS order.
+  // collision_checker.rs:66-101
+  template <class F>
+  void check_env(const std::vector<Iso<T>>& world, const Obstacle<T>& ob, F&& yield, Stats* st,
+                 T* band) const {
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+      for (const LinkShape<T>& ls : link_shapes[ni]) {
+        T d = distance(imul(world[ni], ls.local), ls.shape, ob.pose, ob.shape, st);
+        if (st) st->pair_tests++;
+        if (band) *band = std::min(*band, std::abs(d - margin));
+        if (d < margin) {
+          if (!yield((int)ni)) return;  // has_any_colliding: .next().is_some()
+          if (!band) break;  // the iterator yields the joint once, then moves to the next node
+        }
+      }
+    }
+  }
+
+  // has_any_colliding (joint_path_planner.rs:86-98): obstacle-major, first hit wins.
+  // `redundant_fk` keeps the reference's per-obstacle update_transforms
+  // (collision_checker.rs:54).
+  bool has_any_colliding(const std::vector<T>& pos, std::vector<Iso<T>>& world, bool redundant_fk,
+                         Stats* st) const {
+    if (!redundant_fk) update_transforms(pos, world);
+    for (const Obstacle<T>& ob : obstacles) {
+      if (redundant_fk) update_transforms(pos, world);
+      bool hit = false;
+      check_env(world, ob, [&](int) { hit = true; return false; }, st, nullptr);
+      if (hit) return true;
+    }
+    return false;
+  }
+
+  // SelfCollisionPairs (collision_checker.rs:139-200)
+  template <class F>
+  void check_self(const std::vector<Iso<T>>& world, F&& yield, Stats* st, T* band) const {
+    for (size_t p = 0; p < pairs.size(); p++) {
+      int n1 = pairs[p][0], n2 = pairs[p][1];
+      if (link_shapes[n1].empty() || link_shapes[n2].empty()) continue;
+      bool hit = false;
+      for (const LinkShape<T>& o1 : link_shapes[n1]) {
+        for (const LinkShape<T>& o2 : link_shapes[n2]) {
+          T d = distance(imul(world[n1], o1.local), o1.shape, imul(world[n2], o2.local), o2.shape, st);
+          if (st) st->pair_tests++;
+          if (band) *band = std::min(*band, std::abs(d - margin));
+          if (d < margin) { hit = true; if (!band) break; }
+        }
+        if (hit && !band) break;
+      }
+      if (hit && !yield((int)p)) return;
+    }
+  }
+
+  // flags for one configuration.  faithful = early exits exactly as the
+  // reference's predicates; otherwise every pair is evaluated and *band gets
+  // min |d - margin| over all pairs.
+  uint8_t check_config(const T* q, uint32_t what, bool faithful, bool redundant_fk, T* band,
+                       Stats* st) const {
+    std::vector<T> pos;
+    initial_positions(pos);
+    std::vector<Iso<T>> world;
+    if (band) *band = std::numeric_limits<T>::max();
+    if (!set_joint_positions(q, pos)) return GH_FLAG_LIMIT;
+    uint8_t f = 0;
+    if (faithful) {
+      if (what & GH_CHECK_ENV)
+        if (has_any_colliding(pos, world, redundant_fk, st)) f |= GH_FLAG_ENV;
+      if (what & GH_CHECK_SELF) {
+        update_transforms(pos, world);
+        bool hit = false;
+        check_self(world, [&](int) { hit = true; return false; }, st, nullptr);
+        if (hit) f |= GH_FLAG_SELF;
+      }
+    } else {
+      update_transforms(pos, world);
+      if (what & GH_CHECK_ENV)
+        for (const Obstacle<T>& ob : obstacles)
+          check_env(world, ob, [&](int) { f |= GH_FLAG_ENV; return true; }, st, band);
+      if (what & GH_CHECK_SELF) check_self(world, [&](int) { f |= GH_FLAG_SELF; return true; }, st, band);
+    }
+    return f;
+  }
+};
+
+}  // namespace gear_oracle
