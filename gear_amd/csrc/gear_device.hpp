@@ -1,0 +1,392 @@
+// gear_device.hpp — device-side geometry for gfx950: pose algebra, forward
+// kinematics step, and the narrow-phase "is distance < margin" predicates.
+//
+// What it answers is exactly the reference's test
+//     query::distance(link_pose, link_shape, target_pose, target_shape) < prediction
+// (src/collision/collision_checker.rs:83-92, 177-185) but NOT by running
+// ncollide's GJK to a distance value: the kernel only needs the boolean, so it
+// uses closed forms (ball pairs), a 15-axis separating-axis test with margin
+// (box pairs) and, for what is left, a GJK *margin query* that stops as soon as
+// a lower bound reaches the margin or an upper bound drops below it.  The
+// reference's distance carries GJK's relative tolerance sqrt(10*eps); the two
+// can therefore disagree only when |d - margin| is inside that tolerance band
+// (DESIGN.md "Parity band").
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gear_types.hpp"
+
+namespace gear_hip {
+
+// __host__ too: tests/host_harness.cpp compiles these same functions for the CPU so
+// that the geometry can be unit-tested without a GPU; the product never calls them on the host.
+#define GD __host__ __device__ __forceinline__
+
+template <class T> struct V3 { T x, y, z; };
+template <class T> GD V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> GD V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> GD V3<T> operator-(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <class T> GD V3<T> operator*(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T> GD T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> GD V3<T> cross(V3<T> a, V3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+template <class T> struct Q4 { T i, j, k, w; };
+template <class T> struct Pose { V3<T> t; Q4<T> r; };
+
+template <class T> GD T t_abs(T x) { return x < T(0) ? -x : x; }
+GD float t_copysign(float m, float s) { return copysignf(m, s); }
+GD double t_copysign(double m, double s) { return copysign(m, s); }
+GD float t_sqrt(float x) { return sqrtf(x); }
+GD double t_sqrt(double x) { return sqrt(x); }
+GD void t_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+GD void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+template <class T> GD T t_max(T a, T b) { return a > b ? a : b; }
+template <class T> GD T t_min(T a, T b) { return a < b ? a : b; }
+
+// ---- pose algebra: the formulas nalgebra uses for Isometry3 * Isometry3, kept
+// un-contracted so that node poses track the f32 reference to ~1 ulp ----------
+#pragma clang fp contract(off)
+template <class T> GD Q4<T> qmul(Q4<T> a, Q4<T> b) {
+  return {a.w * b.i + a.i * b.w + a.j * b.k - a.k * b.j,
+          a.w * b.j - a.i * b.k + a.j * b.w + a.k * b.i,
+          a.w * b.k + a.i * b.j - a.j * b.i + a.k * b.w,
+          a.w * b.w - a.i * b.i - a.j * b.j - a.k * b.k};
+}
+template <class T> GD Q4<T> qconj(Q4<T> a) { return {-a.i, -a.j, -a.k, a.w}; }
+template <class T> GD V3<T> qrot(Q4<T> q, V3<T> v) {
+  V3<T> qv{q.i, q.j, q.k};
+  V3<T> t = cross(qv, v) * T(2);
+  V3<T> c = cross(qv, t);
+  return t * q.w + c + v;
+}
+template <class T> GD Pose<T> pose_mul(const Pose<T>& a, const Pose<T>& b) {
+  V3<T> shift = qrot(a.r, b.t);
+  return {a.t + shift, qmul(a.r, b.r)};
+}
+
+// One step of k::Chain::update_transforms: world = parent * (origin * joint(q)).
+template <class T>
+GD Pose<T> fk_step(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position) {
+  Pose<T> local{ot, oq};
+  if (joint_type == JT_ROT) {
+    T s, c;
+    t_sincos(position / T(2), &s, &c);
+    Q4<T> jq{axis.x * s, axis.y * s, axis.z * s, c};
+    local.r = qmul(oq, jq);
+  } else if (joint_type == JT_LIN) {
+    local.t = ot + qrot(oq, axis * position);
+  }
+  return pose_mul(parent, local);
+}
+#pragma clang fp contract(fast)
+
+// ---- relative frame: x_A = R x_B + t ----------------------------------------
+template <class T> struct Rel { T r[9]; V3<T> t; };
+
+template <class T> GD Rel<T> make_rel(const Pose<T>& a, const Pose<T>& b) {
+  Q4<T> ac = qconj(a.r);
+  Q4<T> q = qmul(ac, b.r);
+  Rel<T> rel;
+  rel.t = qrot(ac, b.t - a.t);
+  T ii = q.i * q.i, jj = q.j * q.j, kk = q.k * q.k;
+  T ij = q.i * q.j, ik = q.i * q.k, jk = q.j * q.k;
+  T iw = q.i * q.w, jw = q.j * q.w, kw = q.k * q.w;
+  rel.r[0] = T(1) - T(2) * (jj + kk); rel.r[1] = T(2) * (ij - kw);        rel.r[2] = T(2) * (ik + jw);
+  rel.r[3] = T(2) * (ij + kw);        rel.r[4] = T(1) - T(2) * (ii + kk); rel.r[5] = T(2) * (jk - iw);
+  rel.r[6] = T(2) * (ik - jw);        rel.r[7] = T(2) * (jk + iw);        rel.r[8] = T(1) - T(2) * (ii + jj);
+  return rel;
+}
+template <class T> GD V3<T> rel_mul(const Rel<T>& m, V3<T> v) {  // R v
+  return {m.r[0] * v.x + m.r[1] * v.y + m.r[2] * v.z, m.r[3] * v.x + m.r[4] * v.y + m.r[5] * v.z,
+          m.r[6] * v.x + m.r[7] * v.y + m.r[8] * v.z};
+}
+template <class T> GD V3<T> rel_tmul(const Rel<T>& m, V3<T> v) {  // R^T v
+  return {m.r[0] * v.x + m.r[3] * v.y + m.r[6] * v.z, m.r[1] * v.x + m.r[4] * v.y + m.r[7] * v.z,
+          m.r[2] * v.x + m.r[5] * v.y + m.r[8] * v.z};
+}
+
+// ---- shapes as seen by the narrow phase -----------------------------------
+template <class T> struct ShapeRef {
+  int kind;
+  V3<T> half;  // box half extents; ball: half.x = radius
+  T br;        // bounding radius
+  int vb, vc;  // mesh vertex range
+  int fb, fc;  // mesh plane range
+};
+
+// support point of the CORE shape (ball -> its centre) in shape-local direction d
+template <class T, class VP> GD V3<T> support_core(const ShapeRef<T>& s, VP verts, V3<T> d) {
+  if (s.kind == SK_BOX) return {t_copysign(s.half.x, d.x), t_copysign(s.half.y, d.y), t_copysign(s.half.z, d.z)};
+  if (s.kind == SK_BALL) return {T(0), T(0), T(0)};
+  V3<T> best{verts[3 * s.vb], verts[3 * s.vb + 1], verts[3 * s.vb + 2]};
+  T bd = dot(best, d);
+  for (int j = 1; j < s.vc; j++) {
+    V3<T> p{verts[3 * (s.vb + j)], verts[3 * (s.vb + j) + 1], verts[3 * (s.vb + j) + 2]};
+    T pd = dot(p, d);
+    if (pd > bd) { bd = pd; best = p; }
+  }
+  return best;
+}
+
+// ---- closest point of a simplex to the origin ------------------------------
+// Keeps only the vertices that support the closest feature.  Returns false when
+// the origin is inside a full tetrahedron (shapes intersect).
+// The four points live in named registers (runtime-indexed arrays would be
+// demoted to scratch memory); p0..p(n-1) are valid.
+template <class T> struct Simplex { V3<T> a, b, c, d; int n; };
+
+template <class T> GD V3<T> sel(bool k, V3<T> x, V3<T> y) { return {k ? x.x : y.x, k ? x.y : y.y, k ? x.z : y.z}; }
+
+template <class T> GD void simplex_push(Simplex<T>& s, V3<T> w) {
+  if (s.n == 1) s.b = w;
+  else if (s.n == 2) s.c = w;
+  else s.d = w;
+  s.n++;
+}
+// rebuild from the kept subset (3-bit mask) of (a, b, c)
+template <class T> GD void simplex_set(Simplex<T>& s, V3<T> a, V3<T> b, V3<T> c, int keep) {
+  bool ka = keep & 1, kb = keep & 2, kc = keep & 4;
+  s.a = sel(ka, a, sel(kb, b, c));
+  s.b = sel(ka, sel(kb, b, c), c);
+  s.c = c;
+  s.n = (int)ka + (int)kb + (int)kc;
+}
+
+template <class T> GD void closest_segment(V3<T> a, V3<T> b, V3<T>& v, int& keep) {
+  V3<T> ab = b - a;
+  T t = -dot(a, ab), den = dot(ab, ab);
+  if (t <= T(0)) { v = a; keep = 1; }
+  else if (t >= den) { v = b; keep = 2; }
+  else { v = a + ab * (t / den); keep = 3; }
+}
+
+template <class T> GD void closest_triangle(V3<T> a, V3<T> b, V3<T> c, V3<T>& v, int& keep) {
+  // Ericson, "Real-Time Collision Detection" 5.1.5, query point = origin
+  V3<T> ab = b - a, ac = c - a;
+  T d1 = -dot(ab, a), d2 = -dot(ac, a);
+  if (d1 <= T(0) && d2 <= T(0)) { v = a; keep = 1; return; }
+  T d3 = -dot(ab, b), d4 = -dot(ac, b);
+  if (d3 >= T(0) && d4 <= d3) { v = b; keep = 2; return; }
+  T vc = d1 * d4 - d3 * d2;
+  if (vc <= T(0) && d1 >= T(0) && d3 <= T(0)) { v = a + ab * (d1 / (d1 - d3)); keep = 3; return; }
+  T d5 = -dot(ab, c), d6 = -dot(ac, c);
+  if (d6 >= T(0) && d5 <= d6) { v = c; keep = 4; return; }
+  T vb = d5 * d2 - d1 * d6;
+  if (vb <= T(0) && d2 >= T(0) && d6 <= T(0)) { v = a + ac * (d2 / (d2 - d6)); keep = 5; return; }
+  T va = d3 * d6 - d5 * d4;
+  if (va <= T(0) && (d4 - d3) >= T(0) && (d5 - d6) >= T(0)) {
+    v = b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)));
+    keep = 6;
+    return;
+  }
+  // interior: project the origin on the plane (more robust than barycentric sums)
+  V3<T> n = cross(ab, ac);
+  T nn = dot(n, n);
+  if (nn > T(0)) v = n * (dot(a, n) / nn);
+  else { T den = T(1) / (va + vb + vc); v = a + ab * (vb * den) + ac * (vc * den); }
+  keep = 7;
+}
+
+// one face (a,b,c) of a tetrahedron whose fourth vertex is d: if the origin is on
+// the outer side, offer the face's closest point as a candidate
+template <class T>
+GD void tetra_face(V3<T> a, V3<T> b, V3<T> c, V3<T> d, bool& any, T& best, V3<T>& bv, V3<T>& ta, V3<T>& tb,
+                   V3<T>& tc, int& bkeep) {
+  V3<T> n = cross(b - a, c - a);
+  T sd = dot(n, d - a), so = -dot(n, a);
+  bool outside = (sd == T(0)) || (so * sd < T(0));
+  if (outside) {
+    V3<T> cv;
+    int keep;
+    closest_triangle(a, b, c, cv, keep);
+    T dd = dot(cv, cv);
+    if (!any || dd < best) { best = dd; bv = cv; ta = a; tb = b; tc = c; bkeep = keep; any = true; }
+  }
+}
+
+template <class T> GD bool simplex_closest(Simplex<T>& s, V3<T>& v) {
+  if (s.n == 1) { v = s.a; return true; }
+  if (s.n == 2) {
+    int keep;
+    closest_segment(s.a, s.b, v, keep);
+    simplex_set(s, s.a, s.b, s.b, keep);
+    return true;
+  }
+  if (s.n == 3) {
+    int keep;
+    closest_triangle(s.a, s.b, s.c, v, keep);
+    simplex_set(s, s.a, s.b, s.c, keep);
+    return true;
+  }
+  // tetrahedron: the origin is inside iff it is on the inner side of all four faces
+  bool any = false;
+  T best = T(0);
+  V3<T> bv{0, 0, 0}, ta{}, tb{}, tc{};
+  int bkeep = 0;
+  tetra_face(s.a, s.b, s.c, s.d, any, best, bv, ta, tb, tc, bkeep);
+  tetra_face(s.a, s.c, s.d, s.b, any, best, bv, ta, tb, tc, bkeep);
+  tetra_face(s.a, s.d, s.b, s.c, any, best, bv, ta, tb, tc, bkeep);
+  tetra_face(s.b, s.d, s.c, s.a, any, best, bv, ta, tb, tc, bkeep);
+  if (!any) return false;  // origin enclosed
+  v = bv;
+  simplex_set(s, ta, tb, tc, bkeep);
+  return true;
+}
+
+template <class T> struct Tol;
+template <> struct Tol<float> { static constexpr float rel = 2e-6f; static constexpr int maxit = 40; };
+template <> struct Tol<double> { static constexpr double rel = 1e-13; static constexpr int maxit = 64; };
+
+// GJK margin query between two convex cores in A's frame: true iff
+// dist(coreA, coreB) < m (m > 0).  CSO = A - B.
+template <class T, class VP>
+GD bool gjk_within(const ShapeRef<T>& A, const ShapeRef<T>& B, const Rel<T>& rel, VP verts, T m, int& iters) {
+  const T m2 = m * m;
+  auto cso = [&](V3<T> d) -> V3<T> {  // support of A - B' in direction d (A frame)
+    V3<T> pa = support_core(A, verts, d);
+    V3<T> pb = rel_mul(rel, support_core(B, verts, rel_tmul(rel, -d))) + rel.t;
+    return pa - pb;
+  };
+  V3<T> d0 = -rel.t;  // from B's centre towards A's
+  if (dot(d0, d0) == T(0)) d0 = {T(1), T(0), T(0)};
+  Simplex<T> s;
+  s.a = cso(-d0);  // the CSO point nearest the origin along the centre line
+  s.b = s.c = s.d = s.a;
+  s.n = 1;
+  V3<T> v = s.a;
+  int it = 0;
+  for (; it < Tol<T>::maxit; it++) {
+    T vv = dot(v, v);
+    if (vv < m2) { iters = it; return true; }  // upper bound below the margin
+    V3<T> w = cso(-v);
+    T vw = dot(v, w);
+    // every CSO point x has v.x >= v.w: the distance is at least v.w / |v|
+    if (vw > T(0) && vw * vw >= m2 * vv) { iters = it; return false; }
+    if (vv - vw <= Tol<T>::rel * vv) { iters = it; return false; }  // converged, |v| >= m
+    simplex_push(s, w);
+    if (!simplex_closest(s, v)) { iters = it; return true; }  // origin enclosed: intersecting
+    if (dot(v, v) >= vv) { iters = it; return false; }  // no progress: |v| is the distance
+  }
+  iters = it;
+  return false;
+}
+
+// ---- 15-axis separating-axis test with margin for two boxes ---------------
+// 0: separated by >= m on some axis (free); 1: overlapping (distance 0);
+// 2: 0 <= separation < m on the best axis — needs the exact query.
+template <class T> GD int sat_box_box(V3<T> a, V3<T> b, const Rel<T>& rel, T m) {
+  const T eps = sizeof(T) == 4 ? T(1e-6) : T(1e-12);
+  T ar[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) ar[i] = t_abs(rel.r[i]) + eps;
+  const T* R = rel.r;
+  T tx = rel.t.x, ty = rel.t.y, tz = rel.t.z;
+  bool apart = false;   // some axis shows separation >= m
+  bool gap = false;     // some axis shows separation >= 0
+  T s;
+  // A's face normals
+  s = t_abs(tx) - (a.x + b.x * ar[0] + b.y * ar[1] + b.z * ar[2]); apart |= s >= m; gap |= s >= T(0);
+  s = t_abs(ty) - (a.y + b.x * ar[3] + b.y * ar[4] + b.z * ar[5]); apart |= s >= m; gap |= s >= T(0);
+  s = t_abs(tz) - (a.z + b.x * ar[6] + b.y * ar[7] + b.z * ar[8]); apart |= s >= m; gap |= s >= T(0);
+  // B's face normals
+  s = t_abs(tx * R[0] + ty * R[3] + tz * R[6]) - (b.x + a.x * ar[0] + a.y * ar[3] + a.z * ar[6]); apart |= s >= m; gap |= s >= T(0);
+  s = t_abs(tx * R[1] + ty * R[4] + tz * R[7]) - (b.y + a.x * ar[1] + a.y * ar[4] + a.z * ar[7]); apart |= s >= m; gap |= s >= T(0);
+  s = t_abs(tx * R[2] + ty * R[5] + tz * R[8]) - (b.z + a.x * ar[2] + a.y * ar[5] + a.z * ar[8]); apart |= s >= m; gap |= s >= T(0);
+  // edge x edge axes A_i x B_j (length sqrt(1 - R_ij^2) <= 1): separated by >= m
+  // iff s >= m * len, tested as s >= 0 && s^2 >= m^2 (1 - R_ij^2)
+  const T m2 = m * m;
+#define GEAR_EDGE_AXIS(EXPR, RA, RB, RIJ)                                  \
+  s = t_abs(EXPR) - ((RA) + (RB));                                         \
+  gap |= s >= T(0);                                                        \
+  apart |= (s >= T(0)) && (s * s >= m2 * (T(1) - (RIJ) * (RIJ)));
+  GEAR_EDGE_AXIS(tz * R[3] - ty * R[6], a.y * ar[6] + a.z * ar[3], b.y * ar[2] + b.z * ar[1], R[0])
+  GEAR_EDGE_AXIS(tz * R[4] - ty * R[7], a.y * ar[7] + a.z * ar[4], b.x * ar[2] + b.z * ar[0], R[1])
+  GEAR_EDGE_AXIS(tz * R[5] - ty * R[8], a.y * ar[8] + a.z * ar[5], b.x * ar[1] + b.y * ar[0], R[2])
+  GEAR_EDGE_AXIS(tx * R[6] - tz * R[0], a.x * ar[6] + a.z * ar[0], b.y * ar[5] + b.z * ar[4], R[3])
+  GEAR_EDGE_AXIS(tx * R[7] - tz * R[1], a.x * ar[7] + a.z * ar[1], b.x * ar[5] + b.z * ar[3], R[4])
+  GEAR_EDGE_AXIS(tx * R[8] - tz * R[2], a.x * ar[8] + a.z * ar[2], b.x * ar[4] + b.y * ar[3], R[5])
+  GEAR_EDGE_AXIS(ty * R[0] - tx * R[3], a.x * ar[3] + a.y * ar[0], b.y * ar[8] + b.z * ar[7], R[6])
+  GEAR_EDGE_AXIS(ty * R[1] - tx * R[4], a.x * ar[4] + a.y * ar[1], b.x * ar[8] + b.z * ar[6], R[7])
+  GEAR_EDGE_AXIS(ty * R[2] - tx * R[5], a.x * ar[5] + a.y * ar[2], b.x * ar[7] + b.y * ar[6], R[8])
+#undef GEAR_EDGE_AXIS
+  if (apart) return 0;
+  return gap ? 2 : 1;
+}
+
+// X strictly inside the closed convex mesh P with clearance >= m on every face.
+// A TriMesh is a surface (src/collision/urdf.rs:26-50 builds one for cylinders):
+// a shape that sits inside it without touching a triangle is at a positive
+// distance from it, so the reference reports it free (DESIGN.md "Hollow meshes").
+// p_is_a: P is shape A (frame of `rel`), X is B; else P is B and X is A.
+template <class T, class VP, class PP>
+GD bool inside_with_clearance(const ShapeRef<T>& P, const ShapeRef<T>& X, const Rel<T>& rel, bool p_is_a,
+                              VP verts, PP planes, T m) {
+  if (X.br > T(2) * P.br) return false;  // enclosing-ball argument: X inside P needs br(X) <= 2 br(P)
+  T xr = X.kind == SK_BALL ? X.half.x : T(0);
+  for (int f = 0; f < P.fc; f++) {
+    V3<T> n{planes[4 * (P.fb + f)], planes[4 * (P.fb + f) + 1], planes[4 * (P.fb + f) + 2]};
+    T o = planes[4 * (P.fb + f) + 3];
+    T h;
+    if (p_is_a) {
+      V3<T> px = rel_mul(rel, support_core(X, verts, rel_tmul(rel, n))) + rel.t;
+      h = dot(n, px);
+    } else {
+      V3<T> da = rel_mul(rel, n);
+      V3<T> pa = support_core(X, verts, da);
+      h = dot(da, pa - rel.t);
+    }
+    if (!(o - h - xr >= m)) return false;
+  }
+  return true;
+}
+
+struct LaneCounters { unsigned cull_pass, sat_tests, exact_tests, exact_iters; };
+
+// distance(poseA, A, poseB, B) < margin, for a pair that survived the cull.
+template <class T, bool COUNT, class VP, class PP>
+GD bool pair_within(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, VP verts,
+                    PP planes, T margin, LaneCounters& lc) {
+  if (A.kind == SK_BALL && B.kind == SK_BALL) {
+    // distance_ball_ball, verbatim semantics
+    V3<T> d = wa.t - wb.t;
+    T d2 = dot(d, d), sum = A.half.x + B.half.x;
+    T dist = d2 <= sum * sum ? T(0) : t_sqrt(d2) - sum;
+    return dist < margin;
+  }
+  Rel<T> rel = make_rel(wa, wb);
+  if (A.kind != SK_MESH && B.kind != SK_MESH) {
+    if (A.kind == SK_BOX && B.kind == SK_BOX) {
+      if (COUNT) lc.sat_tests++;
+      int r = sat_box_box(A.half, B.half, rel, margin);
+      if (r != 2) return r == 1 && T(0) < margin;
+      if (COUNT) lc.exact_tests++;
+      int it;
+      bool hit = gjk_within(A, B, rel, verts, margin, it);
+      if (COUNT) lc.exact_iters += it + 1;
+      return hit;
+    }
+    // ball vs box: point-to-box distance in the box's frame
+    V3<T> p, h;
+    T r;
+    if (A.kind == SK_BOX) { p = rel.t; h = A.half; r = B.half.x; }
+    else { p = -rel_tmul(rel, rel.t); h = B.half; r = A.half.x; }
+    V3<T> e{t_max(t_abs(p.x) - h.x, T(0)), t_max(t_abs(p.y) - h.y, T(0)), t_max(t_abs(p.z) - h.z, T(0))};
+    T dist = t_max(t_sqrt(dot(e, e)) - r, T(0));
+    return dist < margin;
+  }
+  if (!(T(0) < margin)) return false;
+  // a convex mesh is involved: margin query on the cores, ball radii folded into the margin
+  T m = margin + (A.kind == SK_BALL ? A.half.x : T(0)) + (B.kind == SK_BALL ? B.half.x : T(0));
+  if (COUNT) lc.exact_tests++;
+  int it;
+  bool hit = gjk_within(A, B, rel, verts, m, it);
+  if (COUNT) lc.exact_iters += it + 1;
+  if (!hit) return false;
+  if (A.kind == SK_MESH && inside_with_clearance(A, B, rel, true, verts, planes, margin)) return false;
+  if (B.kind == SK_MESH && inside_with_clearance(B, A, rel, false, verts, planes, margin)) return false;
+  return true;
+}
+
+}  // namespace gear_hip

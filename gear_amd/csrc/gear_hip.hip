@@ -1,0 +1,441 @@
+// gear_hip.hip — the C ABI of include/gear_hip.h over the gfx950 kernels.
+// Built with: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see gear_amd/build.py).
+// There is no CPU fallback in this library: without a HIP device every compute
+// entry point fails with GH_ERR_NO_DEVICE / GH_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gear_hip.h"
+#include "gear_kernels.hpp"
+#include "gear_scene.hpp"
+
+using namespace gear_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define GH_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(e_ == hipErrorNoDevice ? GH_ERR_NO_DEVICE : GH_ERR_HIP,                    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+// LDS budget per wavefront-workgroup for the per-lane pose columns; beyond it the
+// columns move to a global workspace (chunked launches).
+constexpr size_t kLdsBudget = 40 * 1024;
+constexpr size_t kChunk = size_t(1) << 22;  // configurations per launch when a global store is in use
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return GH_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    GH_HIP(hipMalloc(&p, need));
+    bytes = need;
+    return GH_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct gh_scene {
+  int precision = 32, device = 0;
+  int D = 0, N = 0, L = 0, O = 0, P = 0, n_slots = 0;
+  double margin = 0;
+  SceneDev<float> s32{};
+  SceneDev<double> s64{};
+  std::vector<void*> tables;  // device allocations owned by the scene
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  DevBuf q, flags, out, edges, store, first;
+  CountersDev* counters = nullptr;
+  size_t elem() const { return precision == 32 ? 4 : 8; }
+};
+
+namespace {
+
+template <class U>
+int upload(gh_scene* sc, const std::vector<U>& v, const U** out) {
+  void* d = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(U);
+  GH_HIP(hipMalloc(&d, bytes));
+  sc->tables.push_back(d);
+  if (!v.empty()) GH_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice));
+  *out = (const U*)d;
+  return GH_OK;
+}
+
+template <class T>
+int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_desc& o, double margin, SceneDev<T>& S) {
+  HostTables<T> H;
+  BuildError err{GH_OK, ""};
+  if (!build_tables<T>(r, o, margin, H, err)) return fail(err.code, err.msg);
+  S.n_nodes = (int)H.nodes.size();
+  S.n_cols = r.n_cols;
+  S.n_shapes = (int)H.rshapes.size();
+  S.n_obs = (int)H.oshapes.size();
+  S.n_pairs = (int)H.pairs.size();
+  S.n_limits = (int)H.limits.size();
+  S.n_slots = H.n_slots;
+  S.margin = H.margin;
+  int rc;
+  if ((rc = upload(sc, H.nodes, &S.nodes))) return rc;
+  if ((rc = upload(sc, H.limits, &S.limits))) return rc;
+  if ((rc = upload(sc, H.rshapes, &S.rshapes))) return rc;
+  if ((rc = upload(sc, H.oshapes, &S.oshapes))) return rc;
+  if ((rc = upload(sc, H.ocull, &S.ocull))) return rc;
+  if ((rc = upload(sc, H.pairs, &S.pairs))) return rc;
+  if ((rc = upload(sc, H.verts, &S.verts))) return rc;
+  if ((rc = upload(sc, H.planes, &S.planes))) return rc;
+  sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
+  sc->n_slots = S.n_slots;
+  return GH_OK;
+}
+
+// How many pose columns a launch needs and where they live.
+struct StorePlan {
+  size_t lds_bytes = 0;  // dynamic LDS per workgroup (one wavefront)
+  bool global = false;
+  size_t slots = 0;
+};
+
+StorePlan plan_store(const gh_scene* sc, bool shape_poses) {
+  StorePlan p;
+  p.slots = (size_t)sc->n_slots + (shape_poses ? (size_t)sc->L : 0);
+  size_t bytes = p.slots * 7 * kWave * sc->elem();
+  if (bytes > kLdsBudget) p.global = true;
+  else p.lds_bytes = bytes;
+  return p;
+}
+
+// Runs `launch(offset, count, gstore, gstride)` over [0, n), in chunks when the
+// pose columns live in a global workspace.
+template <class F>
+int for_chunks(gh_scene* sc, size_t n, const StorePlan& plan, F&& launch) {
+  if (n == 0) return GH_OK;
+  if (!plan.global) {
+    launch((size_t)0, n, nullptr, (size_t)0);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
+  size_t chunk = std::min(n, kChunk);
+  size_t stride = (chunk + kWave - 1) / kWave * kWave;
+  int rc = sc->store.ensure(plan.slots * 7 * stride * sc->elem());
+  if (rc) return rc;
+  for (size_t off = 0; off < n; off += chunk) {
+    launch(off, std::min(chunk, n - off), sc->store.p, stride);
+    GH_HIP(hipGetLastError());
+  }
+  return GH_OK;
+}
+
+unsigned grid_for(size_t n) { return (unsigned)((n + kWave - 1) / kWave); }
+
+int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted) {
+  if (!(sc->margin > 0)) what = 0;  // distance >= 0 is never < a non-positive margin: only limits can fail
+  const bool need_shapes = (what & GH_CHECK_SELF) && sc->P > 0;
+  StorePlan plan = plan_store(sc, need_shapes);
+  return for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
+    if (sc->precision == 32) {
+      const float* qq = (const float*)q + off * sc->D;
+      if (counted)
+        hipLaunchKernelGGL((k_check<float, true>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s32, qq,
+                           cnt, what, flags + off, sc->counters, (float*)gs, gstride);
+      else
+        hipLaunchKernelGGL((k_check<float, false>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s32, qq,
+                           cnt, what, flags + off, sc->counters, (float*)gs, gstride);
+    } else {
+      const double* qq = (const double*)q + off * sc->D;
+      if (counted)
+        hipLaunchKernelGGL((k_check<double, true>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s64, qq,
+                           cnt, what, flags + off, sc->counters, (double*)gs, gstride);
+      else
+        hipLaunchKernelGGL((k_check<double, false>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s64, qq,
+                           cnt, what, flags + off, sc->counters, (double*)gs, gstride);
+    }
+  });
+}
+
+int fk_dev(gh_scene* sc, const void* q, size_t n, void* poses, hipStream_t st) {
+  StorePlan plan = plan_store(sc, false);
+  return for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
+    if (sc->precision == 32)
+      hipLaunchKernelGGL((k_fk<float>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s32,
+                         (const float*)q + off * sc->D, cnt, (float*)poses + off * sc->N * 7, (float*)gs, gstride);
+    else
+      hipLaunchKernelGGL((k_fk<double>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s64,
+                         (const double*)q + off * sc->D, cnt, (double*)poses + off * sc->N * 7, (double*)gs, gstride);
+  });
+}
+
+struct Guard {
+  gh_scene* sc;
+  int prev = -1;
+  bool ok = false;
+  explicit Guard(gh_scene* s) : sc(s) {
+    sc->mu.lock();
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(sc->device) == hipSuccess;
+  }
+  ~Guard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+    sc->mu.unlock();
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* gh_last_error(void) { return g_last_error.c_str(); }
+const char* gh_version(void) { return "gear_hip 0.1 (gfx950)"; }
+
+int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacles, double margin, int precision,
+                    int device, gh_scene** out) {
+  if (!robot || !obstacles || !out) return fail(GH_ERR_INVALID, "null argument");
+  if (precision != 32 && precision != 64) return fail(GH_ERR_INVALID, "precision must be 32 or 64");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(GH_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device < 0 || device >= ndev) return fail(GH_ERR_INVALID, "device index out of range");
+  gh_scene* sc = new (std::nothrow) gh_scene;
+  if (!sc) return fail(GH_ERR_INVALID, "out of host memory");
+  sc->precision = precision;
+  sc->device = device;
+  sc->margin = margin;
+  int rc;
+  {
+    Guard g(sc);
+    if (!g.ok) rc = fail(GH_ERR_HIP, "hipSetDevice failed");
+    else {
+      rc = precision == 32 ? build_and_upload<float>(sc, *robot, *obstacles, margin, sc->s32)
+                           : build_and_upload<double>(sc, *robot, *obstacles, margin, sc->s64);
+      if (rc == GH_OK && hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(GH_ERR_HIP, "hipStreamCreate failed");
+      if (rc == GH_OK) {
+        if (hipMalloc((void**)&sc->counters, sizeof(CountersDev)) != hipSuccess ||
+            hipMemset(sc->counters, 0, sizeof(CountersDev)) != hipSuccess)
+          rc = fail(GH_ERR_HIP, "counter allocation failed");
+      }
+    }
+  }
+  if (rc != GH_OK) {
+    std::string keep = g_last_error;
+    gh_scene_destroy(sc);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = sc;
+  return GH_OK;
+}
+
+void gh_scene_destroy(gh_scene* sc) {
+  if (!sc) return;
+  {
+    Guard g(sc);
+    if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
+    for (void* p : sc->tables) (void)hipFree(p);
+    if (sc->counters) (void)hipFree(sc->counters);
+    sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
+  }
+  delete sc;
+}
+
+int gh_scene_dof(const gh_scene* sc) { return sc ? sc->D : GH_ERR_INVALID; }
+int gh_scene_nodes(const gh_scene* sc) { return sc ? sc->N : GH_ERR_INVALID; }
+int gh_scene_precision(const gh_scene* sc) { return sc ? sc->precision : GH_ERR_INVALID; }
+int gh_scene_device(const gh_scene* sc) { return sc ? sc->device : GH_ERR_INVALID; }
+int gh_link_mask_words(const gh_scene* sc) { return sc ? (sc->N + 63) / 64 : GH_ERR_INVALID; }
+
+int gh_check_batch_dev(gh_scene* sc, const void* q_dev, size_t n, uint32_t what, uint8_t* flags_dev, void* stream) {
+  if (!sc || (n && (!q_dev || !flags_dev))) return fail(GH_ERR_INVALID, "null argument");
+  if (n && sc->D == 0) return fail(GH_ERR_DOF_MISMATCH, "scene has no batch columns");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  return check_dev(sc, q_dev, n, what, flags_dev, stream ? (hipStream_t)stream : sc->stream, false);
+}
+
+int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags) {
+  if (!sc || (n && (!q || !flags))) return fail(GH_ERR_INVALID, "null argument");
+  if (n == 0) return GH_OK;
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  int rc;
+  size_t qb = n * sc->D * sc->elem();
+  if ((rc = sc->q.ensure(qb)) || (rc = sc->flags.ensure(n))) return rc;
+  GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
+  if ((rc = check_dev(sc, sc->q.p, n, what, (uint8_t*)sc->flags.p, sc->stream, false))) return rc;
+  GH_HIP(hipMemcpyAsync(flags, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  return GH_OK;
+}
+
+int gh_check_batch_counted(gh_scene* sc, const void* q_dev, size_t n, uint32_t what, uint8_t* flags_dev,
+                           gh_counters* out) {
+  if (!sc || !out || (n && (!q_dev || !flags_dev))) return fail(GH_ERR_INVALID, "null argument");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  GH_HIP(hipMemsetAsync(sc->counters, 0, sizeof(CountersDev), sc->stream));
+  int rc = check_dev(sc, q_dev, n, what, flags_dev, sc->stream, true);
+  if (rc) return rc;
+  CountersDev h;
+  GH_HIP(hipMemcpyAsync(&h, sc->counters, sizeof(h), hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  std::memset(out, 0, sizeof(*out));
+  out->configs = h.configs; out->pairs = h.pairs; out->cull_pass = h.cull_pass;
+  out->sat_tests = h.sat_tests; out->exact_tests = h.exact_tests; out->exact_iters = h.exact_iters;
+  return GH_OK;
+}
+
+int gh_check_edges_dev(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges, size_t n_samples,
+                       uint32_t what, uint8_t bad_mask, uint8_t* flags_dev, int32_t* first_bad_dev, void* stream) {
+  if (!sc || (n_edges && (!edge_off_dev || !first_bad_dev)) || (n_samples && (!q_dev || !flags_dev)))
+    return fail(GH_ERR_INVALID, "null argument");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = stream ? (hipStream_t)stream : sc->stream;
+  int rc = check_dev(sc, q_dev, n_samples, what, flags_dev, st, false);
+  if (rc) return rc;
+  if (n_edges) {
+    hipLaunchKernelGGL(k_edge_first, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st, flags_dev, edge_off_dev,
+                       n_edges, bad_mask, first_bad_dev);
+    GH_HIP(hipGetLastError());
+  }
+  return GH_OK;
+}
+
+int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t n_edges, uint32_t what,
+                   uint8_t bad_mask, uint8_t* flags, int32_t* first_bad) {
+  if (!sc || !edge_off || (n_edges && !first_bad)) return fail(GH_ERR_INVALID, "null argument");
+  if (n_edges == 0) return GH_OK;
+  for (size_t e = 0; e < n_edges; e++)
+    if (edge_off[e + 1] < edge_off[e]) return fail(GH_ERR_INVALID, "edge_off must be non-decreasing");
+  if (edge_off[0] != 0) return fail(GH_ERR_INVALID, "edge_off[0] must be 0");
+  size_t n = edge_off[n_edges];
+  if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
+  int rc;
+  {
+    Guard g(sc);
+    if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+    size_t qb = n * sc->D * sc->elem();
+    if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->flags.ensure(std::max<size_t>(n, 1))) ||
+        (rc = sc->edges.ensure((n_edges + 1) * 4)) || (rc = sc->first.ensure(n_edges * 4)))
+      return rc;
+    if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
+    GH_HIP(hipMemcpyAsync(sc->edges.p, edge_off, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
+  }
+  rc = gh_check_edges_dev(sc, sc->q.p, (const uint32_t*)sc->edges.p, n_edges, n, what, bad_mask, (uint8_t*)sc->flags.p,
+                          (int32_t*)sc->first.p, nullptr);
+  if (rc) return rc;
+  Guard g(sc);
+  if (n) GH_HIP(hipMemcpyAsync(flags, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipMemcpyAsync(first_bad, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  return GH_OK;
+}
+
+int gh_fk_batch_dev(gh_scene* sc, const void* q_dev, size_t n, void* poses_dev, void* stream) {
+  if (!sc || (n && (!q_dev || !poses_dev))) return fail(GH_ERR_INVALID, "null argument");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  return fk_dev(sc, q_dev, n, poses_dev, stream ? (hipStream_t)stream : sc->stream);
+}
+
+int gh_fk_batch(gh_scene* sc, const void* q, size_t n, void* poses) {
+  if (!sc || (n && (!q || !poses))) return fail(GH_ERR_INVALID, "null argument");
+  if (n == 0) return GH_OK;
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  int rc;
+  size_t qb = n * sc->D * sc->elem(), pb = n * sc->N * 7 * sc->elem();
+  if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->out.ensure(pb))) return rc;
+  if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
+  if ((rc = fk_dev(sc, sc->q.p, n, sc->out.p, sc->stream))) return rc;
+  GH_HIP(hipMemcpyAsync(poses, sc->out.p, pb, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  return GH_OK;
+}
+
+int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint64_t* link_mask) {
+  if (!sc || (n && (!q || !link_mask))) return fail(GH_ERR_INVALID, "null argument");
+  if (n == 0 || sc->O == 0) return GH_OK;
+  if (sc->N > 128) return fail(GH_ERR_TOO_LARGE, "gh_link_hits supports at most 128 nodes");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  int W = (sc->N + 63) / 64, rc;
+  size_t qb = n * sc->D * sc->elem(), mb = n * sc->O * W * 8;
+  if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->out.ensure(mb))) return rc;
+  if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
+  if (!(sc->margin > 0)) {
+    GH_HIP(hipMemsetAsync(sc->out.p, 0, mb, sc->stream));
+  } else {
+    StorePlan plan = plan_store(sc, true);
+    rc = for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
+      unsigned long long* m = (unsigned long long*)sc->out.p + off * sc->O * W;
+      if (sc->precision == 32)
+        hipLaunchKernelGGL((k_link_hits<float>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s32,
+                           (const float*)sc->q.p + off * sc->D, cnt, m, W, (float*)gs, gstride);
+      else
+        hipLaunchKernelGGL((k_link_hits<double>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s64,
+                           (const double*)sc->q.p + off * sc->D, cnt, m, W, (double*)gs, gstride);
+    });
+    if (rc) return rc;
+  }
+  GH_HIP(hipMemcpyAsync(link_mask, sc->out.p, mb, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  return GH_OK;
+}
+
+int gh_self_hits(gh_scene* sc, const void* q, size_t n, uint64_t* pair_mask) {
+  if (!sc || (n && (!q || !pair_mask))) return fail(GH_ERR_INVALID, "null argument");
+  if (n == 0 || sc->P == 0) return GH_OK;
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  int W = (sc->P + 63) / 64, rc;
+  size_t qb = n * sc->D * sc->elem(), mb = n * W * 8;
+  if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->out.ensure(mb))) return rc;
+  if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
+  if (!(sc->margin > 0)) {
+    GH_HIP(hipMemsetAsync(sc->out.p, 0, mb, sc->stream));
+  } else {
+    StorePlan plan = plan_store(sc, true);
+    rc = for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
+      unsigned long long* m = (unsigned long long*)sc->out.p + off * W;
+      if (sc->precision == 32)
+        hipLaunchKernelGGL((k_self_hits<float>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s32,
+                           (const float*)sc->q.p + off * sc->D, cnt, m, W, (float*)gs, gstride);
+      else
+        hipLaunchKernelGGL((k_self_hits<double>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s64,
+                           (const double*)sc->q.p + off * sc->D, cnt, m, W, (double*)gs, gstride);
+    });
+    if (rc) return rc;
+  }
+  GH_HIP(hipMemcpyAsync(pair_mask, sc->out.p, mb, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  return GH_OK;
+}
+
+}  // extern "C"

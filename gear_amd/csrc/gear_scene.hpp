@@ -1,0 +1,308 @@
+// gear_scene.hpp — host-side flattening of gh_robot_desc / gh_obstacle_desc into
+// the device tables of gear_types.hpp.  Pure host C++ (no HIP calls): the C ABI
+// layer uploads the resulting vectors.
+//
+// Mirrors, for the hot path only:
+//   k::Chain::from(&urdf_robot) wiring + mimic      (k 0.20, restated)
+//   CollisionChecker::from_urdf_robot_with_base_dir  src/collision/collision_checker.rs:234-262
+//   urdf_geometry_to_shape_handle                    src/collision/urdf.rs:10-73
+//   Compound<f64>::from_urdf_robot                   src/collision/collision_checker.rs:349-369
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/gear_hip.h"
+#include "gear_types.hpp"
+
+namespace gear_hip {
+
+template <class T>
+struct HostTables {
+  std::vector<NodeDev<T>> nodes;
+  std::vector<LimitDev<T>> limits;
+  std::vector<ShapeDev<T>> rshapes, oshapes;
+  std::vector<T> ocull;
+  std::vector<PairDev> pairs;
+  std::vector<T> verts, planes;
+  int n_slots = 0;
+  T margin = 0;
+};
+
+struct BuildError {
+  int code;
+  std::string msg;
+};
+
+namespace detail {
+
+// urdf.rs:26-50: Cylinder(len/2, r).to_trimesh(30), xzy swizzle -> 30-gon prism
+// along Z; angles accumulate by repeated addition in T, as ncollide's
+// procedural push_circle does.
+template <class T>
+inline void make_prism(double radius, double length, std::vector<double>& verts, std::vector<int>& tris) {
+  const int n = 30;
+  T r = T(radius), hh = T(length * 0.5);
+  T dia = r * T(2), hgt = hh * T(2);
+  T dth = T(6.283185307179586476925286766559) * (T(1) / T(n));
+  for (int cap = 0; cap < 2; cap++) {
+    T zc = cap == 0 ? T(-0.5) : T(0.5);
+    T th = 0;
+    for (int i = 0; i < n; i++) {
+      T x = std::cos(th) * T(0.5), y = std::sin(th) * T(0.5);
+      verts.push_back((double)(x * dia));
+      verts.push_back((double)(y * dia));
+      verts.push_back((double)(zc * hgt));
+      th = th + dth;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    int j = (i + 1) % n;
+    tris.insert(tris.end(), {i, j, n + i, j, n + j, n + i});
+  }
+  for (int i = 1; i + 1 < n; i++) {
+    tris.insert(tris.end(), {0, i + 1, i, n, n + i, n + i + 1});
+  }
+}
+
+// Face planes (outward unit normal, offset) of a closed convex triangle mesh;
+// coplanar triangles collapse into one plane.  Returns false (with a reason)
+// when the mesh is not closed or not convex.
+inline bool convex_planes(const std::vector<double>& v, const std::vector<int>& tris, std::vector<double>& planes,
+                          std::string& why) {
+  size_t nv = v.size() / 3, nt = tris.size() / 3;
+  if (nv < 4 || nt < 4) { why = "mesh needs at least 4 vertices and 4 triangles"; return false; }
+  double c[3] = {0, 0, 0}, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (size_t i = 0; i < nv; i++)
+    for (int k = 0; k < 3; k++) {
+      c[k] += v[3 * i + k] / nv;
+      lo[k] = std::min(lo[k], v[3 * i + k]);
+      hi[k] = std::max(hi[k], v[3 * i + k]);
+    }
+  double scale = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
+  if (!(scale > 0)) { why = "degenerate mesh"; return false; }
+  // closed: every undirected edge is shared by exactly two triangles
+  std::map<std::pair<int, int>, int> edges;
+  for (size_t t = 0; t < nt; t++)
+    for (int e = 0; e < 3; e++) {
+      int a = tris[3 * t + e], b = tris[3 * t + (e + 1) % 3];
+      if (a < 0 || b < 0 || a >= (int)nv || b >= (int)nv || a == b) { why = "bad triangle index"; return false; }
+      edges[{std::min(a, b), std::max(a, b)}]++;
+    }
+  for (auto& kv : edges)
+    if (kv.second != 2) { why = "mesh is not closed (an edge is not shared by exactly two triangles)"; return false; }
+  const double tol = 1e-6 * scale;
+  planes.clear();
+  for (size_t t = 0; t < nt; t++) {
+    const double* a = &v[3 * tris[3 * t]];
+    const double* b = &v[3 * tris[3 * t + 1]];
+    const double* d = &v[3 * tris[3 * t + 2]];
+    double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {d[0] - a[0], d[1] - a[1], d[2] - a[2]};
+    double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (nn < 1e-12 * scale * scale) continue;  // sliver: carries no plane
+    for (int k = 0; k < 3; k++) n[k] /= nn;
+    double o = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
+    if (n[0] * c[0] + n[1] * c[1] + n[2] * c[2] > o) { for (int k = 0; k < 3; k++) n[k] = -n[k]; o = -o; }
+    for (size_t i = 0; i < nv; i++)
+      if (n[0] * v[3 * i] + n[1] * v[3 * i + 1] + n[2] * v[3 * i + 2] > o + tol) { why = "mesh is not convex"; return false; }
+    bool dup = false;
+    for (size_t p = 0; p < planes.size() / 4 && !dup; p++)
+      dup = std::fabs(planes[4 * p] - n[0]) < 1e-5 && std::fabs(planes[4 * p + 1] - n[1]) < 1e-5 &&
+            std::fabs(planes[4 * p + 2] - n[2]) < 1e-5 && std::fabs(planes[4 * p + 3] - o) < tol;
+    if (!dup) planes.insert(planes.end(), {n[0], n[1], n[2], o});
+  }
+  if (planes.size() < 16) { why = "mesh has fewer than 4 distinct faces"; return false; }
+  return true;
+}
+
+template <class T>
+inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, int n_meshes, int node,
+                          HostTables<T>& H, ShapeDev<T>& out, BuildError& err) {
+  ShapeDev<T> s{};
+  for (int k = 0; k < 3; k++) s.lt[k] = T(d.t[k]);
+  for (int k = 0; k < 4; k++) s.lq[k] = T(d.q[k]);
+  s.node = node;
+  s.v_begin = s.v_count = s.f_begin = s.f_count = 0;
+  auto bad = [&](const char* m) { err = {GH_ERR_INVALID, m}; return false; };
+  switch (d.kind) {
+    case GH_SHAPE_BOX: {
+      s.kind = SK_BOX;
+      double r2 = 0;
+      for (int k = 0; k < 3; k++) {
+        if (!(d.params[k] > 0)) return bad("box half extents must be positive");
+        s.half[k] = T(d.params[k]);
+        r2 += (double)s.half[k] * (double)s.half[k];
+      }
+      s.br = T(std::sqrt(r2) * (1.0 + 1e-6));
+      break;
+    }
+    case GH_SHAPE_BALL:
+      if (!(d.params[0] > 0)) return bad("ball radius must be positive");
+      s.kind = SK_BALL;
+      s.half[0] = T(d.params[0]);
+      s.br = s.half[0];
+      break;
+    case GH_SHAPE_CYLINDER:
+    case GH_SHAPE_MESH: {
+      std::vector<double> v;
+      std::vector<int> tris;
+      if (d.kind == GH_SHAPE_CYLINDER) {
+        if (!(d.params[0] > 0) || !(d.params[1] > 0)) return bad("cylinder radius and length must be positive");
+        make_prism<T>(d.params[0], d.params[1], v, tris);
+      } else {
+        if (d.mesh < 0 || d.mesh >= n_meshes || !meshes) return bad("mesh index out of range");
+        const gh_mesh_desc& m = meshes[d.mesh];
+        if (m.n_vertices <= 0 || m.n_triangles <= 0 || !m.vertices || !m.triangles) return bad("empty mesh");
+        for (int i = 0; i < 3 * m.n_vertices; i++) v.push_back((double)T(m.vertices[i]));
+        tris.assign(m.triangles, m.triangles + 3 * m.n_triangles);
+      }
+      std::vector<double> planes;
+      std::string why;
+      if (!convex_planes(v, tris, planes, why)) { err = {GH_ERR_NONCONVEX, why}; return false; }
+      s.kind = SK_MESH;
+      s.v_begin = (int)(H.verts.size() / 3);
+      s.v_count = (int)(v.size() / 3);
+      s.f_begin = (int)(H.planes.size() / 4);
+      s.f_count = (int)(planes.size() / 4);
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (size_t i = 0; i < v.size() / 3; i++)
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], v[3 * i + k]); hi[k] = std::max(hi[k], v[3 * i + k]); }
+      double c[3] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2}, r2 = 0;
+      for (size_t i = 0; i < v.size() / 3; i++) {
+        double dd = 0;
+        for (int k = 0; k < 3; k++) dd += (v[3 * i + k] - c[k]) * (v[3 * i + k] - c[k]);
+        r2 = std::max(r2, dd);
+      }
+      for (int k = 0; k < 3; k++) s.bc[k] = T(c[k]);
+      s.br = T(std::sqrt(r2) * (1.0 + 1e-6));
+      for (double x : v) H.verts.push_back(T(x));
+      for (double x : planes) H.planes.push_back(T(x));
+      break;
+    }
+    default:
+      return bad("unknown shape kind");
+  }
+  out = s;
+  return true;
+}
+
+}  // namespace detail
+
+template <class T>
+inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, double margin, HostTables<T>& H,
+                         BuildError& err) {
+  auto bad = [&](const char* m) { err = {GH_ERR_INVALID, m}; return false; };
+  if (r.n_nodes < 1 || !r.nodes) return bad("robot needs at least the root node");
+  if (r.n_cols < 0 || (r.n_cols > 0 && !r.col_node)) return bad("col_node missing");
+  if (r.n_shapes < 0 || (r.n_shapes > 0 && !r.shapes)) return bad("robot shapes missing");
+  if (o.n_shapes < 0 || (o.n_shapes > 0 && !o.shapes)) return bad("obstacle shapes missing");
+  if (r.n_pairs < 0 || (r.n_pairs > 0 && !r.pairs)) return bad("pairs missing");
+  const int N = r.n_nodes;
+  H.margin = T(margin);
+  H.nodes.assign(N, NodeDev<T>{});
+  std::vector<bool> needs_save(N, false);
+  for (int k = 0; k < N; k++) {
+    const gh_node_desc& d = r.nodes[k];
+    if (k == 0 ? d.parent != -1 : (d.parent < 0 || d.parent >= k)) return bad("nodes must be in depth-first order");
+    if (d.joint_type < 0 || d.joint_type > 2) return bad("unknown joint type");
+    if (d.mimic_parent >= N || d.mimic_parent == k) return bad("bad mimic parent");
+    NodeDev<T>& n = H.nodes[k];
+    // k::urdf::axis_from: convert to T, normalise in T
+    T ax[3] = {T(d.axis[0]), T(d.axis[1]), T(d.axis[2])};
+    T an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    for (int j = 0; j < 3; j++) n.axis[j] = an > T(0) ? ax[j] / an : ax[j];
+    if (d.joint_type != GH_JOINT_FIXED && !(an > T(0))) return bad("movable joint with a zero axis");
+    for (int j = 0; j < 3; j++) n.ot[j] = T(d.origin_t[j]);
+    for (int j = 0; j < 4; j++) n.oq[j] = T(d.origin_q[j]);
+    n.joint_type = d.joint_type;
+    n.col = -1;
+    n.direct = 1;
+    n.mult = T(1);
+    n.off = T(0);
+    n.const_pos = T(d.position);
+    n.parent_slot = k == 0 ? PARENT_IDENTITY : PARENT_PREV;
+    n.save_slot = -1;
+    if (k > 0 && d.parent != k - 1) needs_save[d.parent] = true;
+  }
+  H.n_slots = 0;
+  for (int k = 0; k < N; k++)
+    if (needs_save[k]) H.nodes[k].save_slot = H.n_slots++;
+  for (int k = 1; k < N; k++)
+    if (r.nodes[k].parent != k - 1) H.nodes[k].parent_slot = H.nodes[r.nodes[k].parent].save_slot;
+
+  // k::Chain::set_joint_positions, column by column
+  std::vector<std::vector<int>> mimic_children(N);
+  for (int k = 0; k < N; k++)
+    if (r.nodes[k].mimic_parent >= 0) mimic_children[r.nodes[k].mimic_parent].push_back(k);
+  for (int c = 0; c < r.n_cols; c++) {
+    int k = r.col_node[c];
+    if (k < 0 || k >= N) return bad("col_node out of range");
+    const gh_node_desc& d = r.nodes[k];
+    if (d.joint_type == GH_JOINT_FIXED) return bad("a batch column drives a fixed joint (k::Error::SetToFixedError)");
+    if (d.mimic_parent >= 0) continue;  // a mimic joint ignores its own input
+    H.nodes[k].col = c;
+    H.nodes[k].direct = 1;
+    if (d.has_limit) H.limits.push_back({T(1), T(0), T(d.limit_lo), T(d.limit_hi), c, 1});
+    for (int ch : mimic_children[k]) {
+      const gh_node_desc& cd = r.nodes[ch];
+      if (cd.joint_type == GH_JOINT_FIXED) continue;
+      H.nodes[ch].col = c;
+      H.nodes[ch].direct = 0;
+      H.nodes[ch].mult = T(cd.mimic_mult);
+      H.nodes[ch].off = T(cd.mimic_offset);
+      if (cd.has_limit) H.limits.push_back({T(cd.mimic_mult), T(cd.mimic_offset), T(cd.limit_lo), T(cd.limit_hi), c, 0});
+    }
+  }
+
+  // robot shapes grouped by node, keeping the caller's order inside a node
+  std::vector<std::vector<int>> by_node(N);
+  for (int s = 0; s < r.n_shapes; s++) {
+    int k = r.shapes[s].node;
+    if (k < 0 || k >= N) return bad("shape node out of range");
+    by_node[k].push_back(s);
+  }
+  T br_max = 0;
+  for (int k = 0; k < N; k++) {
+    H.nodes[k].shape_begin = (int)H.rshapes.size();
+    for (int s : by_node[k]) {
+      ShapeDev<T> sd;
+      if (!detail::flatten_shape<T>(r.shapes[s], r.meshes, r.n_meshes, k, H, sd, err)) return false;
+      br_max = std::max(br_max, sd.br);
+      H.rshapes.push_back(sd);
+    }
+    H.nodes[k].shape_end = (int)H.rshapes.size();
+  }
+  // obstacles: world poses; cull record = world bounding sphere, radius pre-inflated by the margin
+  for (int s = 0; s < o.n_shapes; s++) {
+    ShapeDev<T> sd;
+    if (!detail::flatten_shape<T>(o.shapes[s], o.meshes, o.n_meshes, -1, H, sd, err)) return false;
+    H.oshapes.push_back(sd);
+    // centre = t + R(q) * bc, in double
+    double q[4] = {(double)sd.lq[0], (double)sd.lq[1], (double)sd.lq[2], (double)sd.lq[3]};
+    double b[3] = {(double)sd.bc[0], (double)sd.bc[1], (double)sd.bc[2]};
+    double tx = 2 * (q[1] * b[2] - q[2] * b[1]), ty = 2 * (q[2] * b[0] - q[0] * b[2]), tz = 2 * (q[0] * b[1] - q[1] * b[0]);
+    double cx = b[0] + q[3] * tx + (q[1] * tz - q[2] * ty);
+    double cy = b[1] + q[3] * ty + (q[2] * tx - q[0] * tz);
+    double cz = b[2] + q[3] * tz + (q[0] * ty - q[1] * tx);
+    H.ocull.push_back(T((double)sd.lt[0] + cx));
+    H.ocull.push_back(T((double)sd.lt[1] + cy));
+    H.ocull.push_back(T((double)sd.lt[2] + cz));
+    double rr = (double)sd.br + std::max(margin, 0.0);
+    H.ocull.push_back(T(rr + 1e-4 * (rr + (double)br_max) + 1e-9));
+  }
+  // self pairs -> shape ranges; a pair whose joint has no model never yields
+  // (collision_checker.rs:150-159)
+  for (int p = 0; p < r.n_pairs; p++) {
+    int a = r.pairs[2 * p], b = r.pairs[2 * p + 1];
+    if (a < 0 || a >= N || b < 0 || b >= N) return bad("self pair node out of range");
+    PairDev pd{H.nodes[a].shape_begin, H.nodes[a].shape_end, H.nodes[b].shape_begin, H.nodes[b].shape_end};
+    H.pairs.push_back(pd);  // an empty range simply never hits; pair indices stay the caller's
+  }
+  return true;
+}
+
+}  // namespace gear_hip

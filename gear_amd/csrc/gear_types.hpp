@@ -1,0 +1,84 @@
+// gear_types.hpp — plain tables shared by the host-side scene builder and the
+// gfx950 kernels.  A gh_scene is these tables, flattened once at
+// gh_scene_create and resident in HBM for the life of the scene.
+#pragma once
+#include <stdint.h>
+
+namespace gear_hip {
+
+enum : int { SK_BOX = 0, SK_BALL = 1, SK_MESH = 2 };
+enum : int { JT_FIXED = 0, JT_ROT = 1, JT_LIN = 2 };
+
+// Where a node's parent world pose comes from during the depth-first FK walk.
+enum : int { PARENT_PREV = -1, PARENT_IDENTITY = -2 };
+
+// One k::Node (reference: k::Chain::update_transforms, called at
+// src/collision/collision_checker.rs:54,124).
+template <class T>
+struct NodeDev {
+  T ot[3];          // joint origin translation
+  T oq[4];          // joint origin rotation (i,j,k,w)
+  T axis[3];        // unit joint axis
+  T mult, off;      // mimic: position = off + mult * q[col]
+  T const_pos;      // position when no batch column drives the node
+  int32_t joint_type;
+  int32_t col;         // driving batch column, -1: constant
+  int32_t direct;      // 1: position = q[col] exactly (not through a mimic)
+  int32_t parent_slot; // PARENT_PREV, PARENT_IDENTITY or LDS slot holding the parent's world pose
+  int32_t save_slot;   // LDS slot to keep this node's world pose in, -1: none
+  int32_t shape_begin, shape_end;  // robot shapes owned by this node
+  int32_t pad;
+};
+
+// One k::joint::Range::is_valid check (k::Chain::set_joint_positions, called at
+// src/planner/joint_path_planner.rs:77,114).
+template <class T>
+struct LimitDev {
+  T mult, off, lo, hi;
+  int32_t col;
+  int32_t direct;
+};
+
+// One (ShapeHandle, Isometry3) — robot shapes carry a node-local pose, obstacle
+// shapes a world pose (src/collision/collision_checker.rs:30, 349-369).
+template <class T>
+struct ShapeDev {
+  T lt[3];    // pose translation
+  T lq[4];    // pose rotation (i,j,k,w)
+  T half[3];  // box half extents; ball: half[0] = radius
+  T bc[3];    // bounding-sphere centre, shape-local
+  T br;       // bounding-sphere radius
+  int32_t kind;
+  int32_t node;
+  int32_t v_begin, v_count;  // mesh vertices  (T[3] each) in the scene's vertex pool
+  int32_t f_begin, f_count;  // mesh face planes (nx,ny,nz,offset) in the plane pool
+  int32_t pad[2];
+};
+
+struct PairDev {
+  int32_t s1_begin, s1_end;  // shapes of joint 1
+  int32_t s2_begin, s2_end;  // shapes of joint 2
+};
+
+struct CountersDev {
+  unsigned long long configs, pairs, cull_pass, sat_tests, exact_tests, exact_iters, r0, r1;
+};
+
+// Everything a kernel needs, passed by value.  Table pointers are re-qualified
+// into the constant address space inside the kernels so that wave-uniform
+// reads go through the scalar cache.
+template <class T>
+struct SceneDev {
+  int32_t n_nodes, n_cols, n_shapes, n_obs, n_pairs, n_limits, n_slots, pad;
+  T margin;
+  const NodeDev<T>* nodes;
+  const LimitDev<T>* limits;
+  const ShapeDev<T>* rshapes;
+  const ShapeDev<T>* oshapes;
+  const T* ocull;  // [n_obs][4]: world bounding sphere cx,cy,cz and radius + margin (pre-inflated)
+  const PairDev* pairs;
+  const T* verts;   // [..][3]
+  const T* planes;  // [..][4]
+};
+
+}  // namespace gear_hip

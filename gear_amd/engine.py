@@ -1,0 +1,162 @@
+"""ctypes binding of libgear_hip.so — the C ABI declared in include/gear_hip.h.
+
+The HIP library is the only compute path: if it is missing, or no MI355X/HIP
+device is present, construction raises; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import descriptors as D
+from .build import LIB_PATH
+
+_LIB = None
+
+SYMBOLS = [
+    "gh_scene_create", "gh_scene_destroy", "gh_scene_dof", "gh_scene_nodes", "gh_scene_precision",
+    "gh_scene_device", "gh_check_batch", "gh_check_batch_dev", "gh_check_edges", "gh_check_edges_dev",
+    "gh_fk_batch", "gh_fk_batch_dev", "gh_link_hits", "gh_link_mask_words", "gh_self_hits",
+    "gh_check_batch_counted", "gh_last_error", "gh_version",
+]
+
+
+class GearHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"gear_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GearHipError(-3, f"{LIB_PATH} is missing: run `python -m gear_amd.build` (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        vp, sz, u32, u8 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8
+        L.gh_scene_create.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int, C.POINTER(vp)]
+        L.gh_scene_destroy.argtypes = [vp]
+        L.gh_scene_destroy.restype = None
+        for name in ("gh_scene_dof", "gh_scene_nodes", "gh_scene_precision", "gh_scene_device", "gh_link_mask_words"):
+            getattr(L, name).argtypes = [vp]
+        L.gh_check_batch.argtypes = [vp, vp, sz, u32, vp]
+        L.gh_check_batch_dev.argtypes = [vp, vp, sz, u32, vp, vp]
+        L.gh_check_edges.argtypes = [vp, vp, vp, sz, u32, u8, vp, vp]
+        L.gh_check_edges_dev.argtypes = [vp, vp, vp, sz, sz, u32, u8, vp, vp, vp]
+        L.gh_fk_batch.argtypes = [vp, vp, sz, vp]
+        L.gh_fk_batch_dev.argtypes = [vp, vp, sz, vp, vp]
+        L.gh_link_hits.argtypes = [vp, vp, sz, vp]
+        L.gh_self_hits.argtypes = [vp, vp, sz, vp]
+        L.gh_check_batch_counted.argtypes = [vp, vp, sz, u32, vp, vp]
+        L.gh_last_error.restype = C.c_char_p
+        L.gh_version.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise GearHipError(rc, lib().gh_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Scene:
+    """An immutable robot + obstacle scene resident in HBM (gh_scene)."""
+
+    def __init__(self, robot_keep, obstacle_keep, margin: float, precision: int = 32, device: int = 0):
+        self._keep = (robot_keep, obstacle_keep)
+        self.h = C.c_void_p()
+        _check(lib().gh_scene_create(C.addressof(robot_keep.desc), C.addressof(obstacle_keep.desc), float(margin),
+                                     int(precision), int(device), C.byref(self.h)))
+        self.precision = precision
+        self.dtype = np.float32 if precision == 32 else np.float64
+        self.device = device
+        self.margin = margin
+        self.dof = lib().gh_scene_dof(self.h)
+        self.n_nodes = lib().gh_scene_nodes(self.h)
+        self.n_obstacles = obstacle_keep.desc.n_shapes
+        self.n_pairs = robot_keep.desc.n_pairs
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gh_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer entry points (numpy) ----
+    def _q(self, q):
+        q = np.ascontiguousarray(q, dtype=self.dtype)
+        if q.ndim != 2 or q.shape[1] != self.dof:
+            raise GearHipError(-2, f"DoF mismatch {q.shape[-1] if q.ndim else 0} != {self.dof}")
+        return q
+
+    def check_batch(self, q, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF) -> np.ndarray:
+        q = self._q(q)
+        flags = np.zeros(q.shape[0], np.uint8)
+        _check(lib().gh_check_batch(self.h, _ptr(q), q.shape[0], what, _ptr(flags)))
+        return flags
+
+    def check_edges(self, q, edge_off, what=D.GH_CHECK_ENV, bad_mask=D.GH_FLAG_ENV | D.GH_FLAG_LIMIT):
+        q = self._q(q)
+        edge_off = np.ascontiguousarray(edge_off, np.uint32)
+        E = len(edge_off) - 1
+        if E >= 0 and len(edge_off) and int(edge_off[-1]) != q.shape[0]:
+            raise GearHipError(-1, "edge_off[-1] must equal the number of samples")
+        flags = np.zeros(q.shape[0], np.uint8)
+        first_bad = np.full(max(E, 0), -1, np.int32)
+        _check(lib().gh_check_edges(self.h, _ptr(q), _ptr(edge_off), max(E, 0), what, bad_mask, _ptr(flags),
+                                    _ptr(first_bad)))
+        return flags, first_bad
+
+    def fk_batch(self, q) -> np.ndarray:
+        q = self._q(q)
+        poses = np.zeros((q.shape[0], self.n_nodes, 7), self.dtype)
+        _check(lib().gh_fk_batch(self.h, _ptr(q), q.shape[0], _ptr(poses)))
+        return poses
+
+    def link_hits(self, q) -> np.ndarray:
+        q = self._q(q)
+        W = lib().gh_link_mask_words(self.h)
+        m = np.zeros((q.shape[0], self.n_obstacles, W), np.uint64)
+        _check(lib().gh_link_hits(self.h, _ptr(q), q.shape[0], _ptr(m)))
+        return m
+
+    def self_hits(self, q) -> np.ndarray:
+        q = self._q(q)
+        W = max((self.n_pairs + 63) // 64, 1)
+        m = np.zeros((q.shape[0], W), np.uint64)
+        _check(lib().gh_self_hits(self.h, _ptr(q), q.shape[0], _ptr(m)))
+        return m
+
+    # ---- device-buffer entry points (torch tensors on this scene's device) ----
+    def check_batch_dev(self, q_t, flags_t, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF, stream: Optional[int] = None):
+        n = q_t.shape[0]
+        assert q_t.is_contiguous() and flags_t.is_contiguous() and q_t.shape[1] == self.dof and flags_t.numel() >= n
+        _check(lib().gh_check_batch_dev(self.h, q_t.data_ptr(), n, what, flags_t.data_ptr(), stream))
+
+    def check_edges_dev(self, q_t, edge_off_t, flags_t, first_bad_t, what=D.GH_CHECK_ENV,
+                        bad_mask=D.GH_FLAG_ENV | D.GH_FLAG_LIMIT, stream: Optional[int] = None):
+        n, E = q_t.shape[0], edge_off_t.numel() - 1
+        _check(lib().gh_check_edges_dev(self.h, q_t.data_ptr(), edge_off_t.data_ptr(), E, n, what, bad_mask,
+                                        flags_t.data_ptr(), first_bad_t.data_ptr(), stream))
+
+    def fk_batch_dev(self, q_t, poses_t, stream: Optional[int] = None):
+        _check(lib().gh_fk_batch_dev(self.h, q_t.data_ptr(), q_t.shape[0], poses_t.data_ptr(), stream))
+
+    def check_batch_counted(self, q_t, flags_t, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF) -> dict:
+        c = D.gh_counters()
+        _check(lib().gh_check_batch_counted(self.h, q_t.data_ptr(), q_t.shape[0], what, flags_t.data_ptr(),
+                                            C.byref(c)))
+        return {k: int(getattr(c, k)) for k in ("configs", "pairs", "cull_pass", "sat_tests", "exact_tests",
+                                                "exact_iters")}

@@ -47,6 +47,8 @@ def lib():
         L.orc_self_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_distance.restype = C.c_double
         L.orc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_distance_bounds.restype = C.c_double
+        L.orc_distance_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_project_simplex.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_cylinder_vertices.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_quat_from_rpy.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p]
@@ -86,11 +88,12 @@ class OracleScene:
 
     def check(self, q, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF, faithful=False, redundant_fk=False,
               threads=1, want_band=True, want_stats=False):
-        """flags (and, when not faithful, band = min |d - margin| over all pairs)."""
+        """flags and, when not faithful, band[n][2]: band[:,0] = min |d - margin| over all pairs,
+        band[:,1] = min (certified lower bound - margin) over pairs the oracle reports free."""
         q = self._q(q)
         n = q.shape[0]
         flags = np.zeros(n, np.uint8)
-        band = np.zeros(n, np.float64) if (want_band and not faithful) else None
+        band = np.zeros((n, 2), np.float64) if (want_band and not faithful) else None
         stats = np.zeros(3, np.uint64) if want_stats else None
         lib().orc_check(self.h, _ptr(q), n, what, int(faithful), int(redundant_fk), threads, _ptr(flags),
                         _ptr(band), _ptr(stats))
@@ -137,6 +140,17 @@ def distance(spec_a: D.ShapeSpec, spec_b: D.ShapeSpec, precision: int = 64) -> f
     sa, ma, _ = D._fill_shapes([(-1, spec_a)], refs)
     sb, mb, _ = D._fill_shapes([(-1, spec_b)], refs)
     return lib().orc_distance(C.addressof(sa), C.addressof(ma), C.addressof(sb), C.addressof(mb), precision)
+
+
+def distance_bounds(spec_a: D.ShapeSpec, spec_b: D.ShapeSpec, precision: int = 64):
+    """(distance as the restated reference returns it, lower bound its GJK run certified)."""
+    refs = []
+    sa, ma, _ = D._fill_shapes([(-1, spec_a)], refs)
+    sb, mb, _ = D._fill_shapes([(-1, spec_b)], refs)
+    lo = C.c_double(0.0)
+    d = lib().orc_distance_bounds(C.addressof(sa), C.addressof(ma), C.addressof(sb), C.addressof(mb), precision,
+                                  C.byref(lo))
+    return d, lo.value
 
 
 def project_simplex(points) -> np.ndarray:

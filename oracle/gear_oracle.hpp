@@ -429,6 +429,8 @@ struct GjkResult {
   GjkKind kind;
   V3<T> p1, p2;
   int iters;
+  T lower;  // best certified lower bound on the distance seen by the run (oracle-side diagnostic,
+            // not part of ncollide's result): the true distance lies in [lower, |p1 - p2|]
 };
 
 template <class T>
@@ -454,7 +456,7 @@ inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, con
                                        const Shape<T>& g2, VoronoiSimplex<T>& simplex) {
   const T tol = eps_tol<T>();
   const T rel = std::sqrt(tol);
-  GjkResult<T> res{GJK_INTERSECTION, {0, 0, 0}, {0, 0, 0}, 0};
+  GjkResult<T> res{GJK_INTERSECTION, {0, 0, 0}, {0, 0, 0}, 0, T(0)};
   V3<T> proj = simplex.project_origin_and_reduce();
   T n2 = norm2(proj);
   if (!(n2 > T(0))) return res;
@@ -482,6 +484,7 @@ inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, con
     }
     CSOPoint<T> cso = cso_from_shapes(m1, g1, m2, g2, dir);
     T min_bound = -dot(dir, cso.point);
+    if (min_bound > res.lower) res.lower = min_bound;
     if (max_bound - min_bound <= rel * max_bound) {
       res.kind = GJK_CLOSEST;
       gjk_witness(simplex, false, res.p1, res.p2);
@@ -522,7 +525,7 @@ struct Stats {
 // distance_support_map_support_map
 template <class T>
 inline T distance_support_maps(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2,
-                               const Shape<T>& g2, Stats* st = nullptr) {
+                               const Shape<T>& g2, Stats* st = nullptr, T* lower = nullptr) {
   V3<T> dir = m1.t - m2.t;
   T n2 = norm2(dir);
   T e = std::numeric_limits<T>::epsilon();
@@ -532,6 +535,7 @@ inline T distance_support_maps(const Iso<T>& m1, const Shape<T>& g1, const Iso<T
   simplex.reset(cso_from_shapes(m1, g1, m2, g2, dir));
   GjkResult<T> r = gjk_closest_points(m1, g1, m2, g2, simplex);
   if (st) { st->gjk_calls++; st->gjk_iters += (uint64_t)r.iters + 1; }
+  if (lower) *lower = r.kind == GJK_CLOSEST ? r.lower : T(0);
   if (r.kind == GJK_CLOSEST) return norm(r.p1 - r.p2);
   return T(0);  // Intersection, or "GJK did not converge"
 }
@@ -620,59 +624,86 @@ template <class T> inline T aabb_msum_dist(const AABB<T>& bv, V3<T> shift, V3<T>
 }
 
 template <class T>
-T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2, Stats* st);
+T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2, Stats* st,
+           T* lower = nullptr);
 
 // distance_composite_shape_shape(m1, mesh g1, m2, g2): min over triangles of g1
 template <class T>
 inline T distance_composite(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2,
-                            bool swapped, Stats* st) {
+                            bool swapped, Stats* st, T* lower) {
   Iso<T> ls_m2 = imul(iinv(m1), m2);
   AABB<T> bb2 = aabb_of(g2, ls_m2);
   V3<T> shift = -((bb2.lo + bb2.hi) * T(0.5));
   V3<T> marg = (bb2.hi - bb2.lo) * T(0.5);
   T best = std::numeric_limits<T>::max();
-  int stack[128];
-  int sp = 0;
-  stack[sp++] = 0;
+  T best_lower = std::numeric_limits<T>::max();
+  // BVH::best_first_search: visit nodes in order of increasing AABB bound, stop
+  // once the smallest pending bound cannot beat the best distance found.
+  struct Ent { T cost; int id; };
+  Ent heap[256];
+  int hn = 0;
+  auto push = [&](T cost, int id) {
+    int i = hn++;
+    heap[i] = {cost, id};
+    while (i > 0 && heap[(i - 1) / 2].cost > heap[i].cost) { std::swap(heap[(i - 1) / 2], heap[i]); i = (i - 1) / 2; }
+  };
+  auto pop = [&]() {
+    Ent top = heap[0];
+    heap[0] = heap[--hn];
+    int i = 0;
+    for (;;) {
+      int l = 2 * i + 1, r = l + 1, m = i;
+      if (l < hn && heap[l].cost < heap[m].cost) m = l;
+      if (r < hn && heap[r].cost < heap[m].cost) m = r;
+      if (m == i) break;
+      std::swap(heap[m], heap[i]);
+      i = m;
+    }
+    return top;
+  };
   Shape<T> tri;
   tri.kind = K_TRI;
-  while (sp > 0) {
-    int id = stack[--sp];
-    const BvhNode<T>& nd = g1.bvh[id];
-    T lb = aabb_msum_dist(nd.bb, shift, marg);
-    if (!(lb < best)) continue;
+  push(aabb_msum_dist(g1.bvh[0].bb, shift, marg), 0);
+  while (hn > 0) {
+    Ent e = pop();
+    if (!(e.cost < best)) break;
+    const BvhNode<T>& nd = g1.bvh[e.id];
     if (nd.left < 0) {
       const auto& t = g1.tris[nd.tri];
       tri.a = g1.verts[t[0]];
       tri.b = g1.verts[t[1]];
       tri.c = g1.verts[t[2]];
       // map_part_at hands (m1, triangle); argument order follows the caller's
-      T d = swapped ? distance(m2, g2, m1, tri, st) : distance(m1, tri, m2, g2, st);
+      T lo = 0;
+      T d = swapped ? distance(m2, g2, m1, tri, st, &lo) : distance(m1, tri, m2, g2, st, &lo);
       if (d < best) best = d;
+      if (lo < best_lower) best_lower = lo;
     } else {
       T ll = aabb_msum_dist(g1.bvh[nd.left].bb, shift, marg);
       T lr = aabb_msum_dist(g1.bvh[nd.right].bb, shift, marg);
-      // visit the nearer child first
-      if (ll <= lr) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
-      else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
+      if (ll < best && hn < 255) push(ll, nd.left);
+      if (lr < best && hn < 255) push(lr, nd.right);
     }
   }
+  // pruned triangles have an AABB bound >= the best distance at the time, hence >= best_lower
+  if (lower) *lower = std::min(best_lower, best);
   return best;
 }
 
 // ncollide3d::query::distance dispatch
 template <class T>
-T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2, Stats* st) {
+T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T>& g2, Stats* st, T* lower) {
   if (g1.kind == K_BALL && g2.kind == K_BALL) {
     // distance_ball_ball
     T d2 = norm2(m1.t - m2.t);
     T sum = g1.radius + g2.radius;
-    if (d2 <= sum * sum) return T(0);
-    return std::sqrt(d2) - sum;
+    T d = d2 <= sum * sum ? T(0) : std::sqrt(d2) - sum;
+    if (lower) *lower = d;
+    return d;
   }
-  if (g1.kind != K_MESH && g2.kind != K_MESH) return distance_support_maps(m1, g1, m2, g2, st);
-  if (g1.kind == K_MESH) return distance_composite(m1, g1, m2, g2, false, st);
-  return distance_composite(m2, g2, m1, g1, true, st);
+  if (g1.kind != K_MESH && g2.kind != K_MESH) return distance_support_maps(m1, g1, m2, g2, st, lower);
+  if (g1.kind == K_MESH) return distance_composite(m1, g1, m2, g2, false, st, lower);
+  return distance_composite(m2, g2, m1, g1, true, st, lower);
 }
 
 // ---------------------------------------------------------------------------
@@ -872,6 +903,15 @@ struct Scene {
     }
   }
 
+  // oracle-side diagnostics for the parity band: band[0] = min |d - margin| over pairs,
+  // band[1] = min (lower - margin) over pairs reported free (d >= margin): negative
+  // means GJK stopped before its own bounds certified "free" for that pair.
+  void note_band(T* band, T d, T lo) const {
+    if (!band) return;
+    band[0] = std::min(band[0], std::abs(d - margin));
+    if (!(d < margin)) band[1] = std::min(band[1], lo - margin);
+  }
+
   // EnvCollisionNames for one obstacle: node-index list in DFS order.
   // collision_checker.rs:66-101
   template <class F>
@@ -879,9 +919,10 @@ struct Scene {
                  T* band) const {
     for (size_t ni = 0; ni < nodes.size(); ni++) {
       for (const LinkShape<T>& ls : link_shapes[ni]) {
-        T d = distance(imul(world[ni], ls.local), ls.shape, ob.pose, ob.shape, st);
+        T lo = 0;
+        T d = distance(imul(world[ni], ls.local), ls.shape, ob.pose, ob.shape, st, band ? &lo : nullptr);
         if (st) st->pair_tests++;
-        if (band) *band = std::min(*band, std::abs(d - margin));
+        note_band(band, d, lo);
         if (d < margin) {
           if (!yield((int)ni)) return;  // has_any_colliding: .next().is_some()
           if (!band) break;  // the iterator yields the joint once, then moves to the next node
@@ -914,9 +955,11 @@ struct Scene {
       bool hit = false;
       for (const LinkShape<T>& o1 : link_shapes[n1]) {
         for (const LinkShape<T>& o2 : link_shapes[n2]) {
-          T d = distance(imul(world[n1], o1.local), o1.shape, imul(world[n2], o2.local), o2.shape, st);
+          T lo = 0;
+          T d = distance(imul(world[n1], o1.local), o1.shape, imul(world[n2], o2.local), o2.shape, st,
+                         band ? &lo : nullptr);
           if (st) st->pair_tests++;
-          if (band) *band = std::min(*band, std::abs(d - margin));
+          note_band(band, d, lo);
           if (d < margin) { hit = true; if (!band) break; }
         }
         if (hit && !band) break;
@@ -933,7 +976,7 @@ struct Scene {
     std::vector<T> pos;
     initial_positions(pos);
     std::vector<Iso<T>> world;
-    if (band) *band = std::numeric_limits<T>::max();
+    if (band) band[0] = band[1] = std::numeric_limits<T>::max();
     if (!set_joint_positions(q, pos)) return GH_FLAG_LIMIT;
     uint8_t f = 0;
     if (faithful) {

@@ -38,10 +38,10 @@ static void do_check(const Scene<T>& s, const T* q, size_t n, uint32_t what, int
   std::vector<Stats> st(std::max(threads, 1));
   parallel_for(n, threads, [&](size_t lo, size_t hi, int t) {
     for (size_t i = lo; i < hi; i++) {
-      T b;
+      T b[2];
       flags[i] = s.check_config(q + i * D, what, faithful != 0, redundant_fk != 0,
-                                band ? &b : nullptr, stats ? &st[t] : nullptr);
-      if (band) band[i] = (double)b;
+                                band ? b : nullptr, stats ? &st[t] : nullptr);
+      if (band) { band[2 * i] = (double)b[0]; band[2 * i + 1] = (double)b[1]; }
     }
   });
   if (stats) {
@@ -200,6 +200,20 @@ double orc_distance(const gh_shape_desc* a, const gh_mesh_desc* meshes_a, const 
   }
   Shape<double> sa = make_shape<double>(*a, meshes_a), sb = make_shape<double>(*b, meshes_b);
   return distance(make_iso<double>(a->t, a->q), sa, make_iso<double>(b->t, b->q), sb, (Stats*)nullptr);
+}
+
+// same, also returning the run's certified lower bound (true distance in [*lower, result])
+double orc_distance_bounds(const gh_shape_desc* a, const gh_mesh_desc* meshes_a, const gh_shape_desc* b,
+                           const gh_mesh_desc* meshes_b, int precision, double* lower) {
+  if (precision == 32) {
+    Shape<float> sa = make_shape<float>(*a, meshes_a), sb = make_shape<float>(*b, meshes_b);
+    float lo = 0;
+    float d = distance(make_iso<float>(a->t, a->q), sa, make_iso<float>(b->t, b->q), sb, (Stats*)nullptr, &lo);
+    *lower = lo;
+    return d;
+  }
+  Shape<double> sa = make_shape<double>(*a, meshes_a), sb = make_shape<double>(*b, meshes_b);
+  return distance(make_iso<double>(a->t, a->q), sa, make_iso<double>(b->t, b->q), sb, (Stats*)nullptr, lower);
 }
 
 // closest point to the origin on a simplex of n (1..4) points, through the

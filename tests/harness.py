@@ -1,0 +1,34 @@
+"""Builds and loads tests/libhost_harness.so (the product's narrow phase compiled for the CPU;
+test harness only)."""
+import ctypes as C
+import os
+import subprocess
+
+from gear_amd import descriptors as D
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libhost_harness.so")
+        src = os.path.join(_HERE, "host_harness.cpp")
+        deps = [src] + [os.path.join(_HERE, "..", "gear_amd", "csrc", f)
+                        for f in ("gear_device.hpp", "gear_scene.hpp", "gear_types.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
+                                   "-o", so, src])
+        _LIB = C.CDLL(so)
+        _LIB.hh_pair_within.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_double, C.c_int]
+    return _LIB
+
+
+def pair_within(a: D.ShapeSpec, b: D.ShapeSpec, margin: float, precision: int) -> int:
+    refs = []
+    sa, ma, na = D._fill_shapes([(-1, a)], refs)
+    sb, mb, nb = D._fill_shapes([(-1, b)], refs)
+    return lib().hh_pair_within(C.addressof(sa), C.addressof(ma), na, C.addressof(sb), C.addressof(mb), nb,
+                                margin, precision)

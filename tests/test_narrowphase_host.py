@@ -1,0 +1,124 @@
+"""The product's narrow phase (SAT / closed forms / GJK margin query / hollow-mesh rule),
+compiled for the CPU by tests/harness.py, against the oracle's restated
+ncollide3d::query::distance on random shape pairs.  Flags must agree except
+inside the stated band around the margin (DESIGN.md "Parity band")."""
+import math
+
+import numpy as np
+import pytest
+
+from gear_amd.descriptors import ShapeSpec
+from gear_amd.urdf import quat_from_rpy
+from oracle import binding as orc
+from tests import harness
+
+MARGIN = 0.01
+BAND = {32: 2e-5, 64: 1e-9}
+
+
+def rand_convex_mesh(rng, scale):
+    from scipy.spatial import ConvexHull
+    pts = rng.normal(size=(int(rng.integers(8, 24)), 3))
+    pts *= scale * rng.uniform(0.5, 1.0, 3) / np.linalg.norm(pts, axis=1, keepdims=True)
+    hull = ConvexHull(pts)
+    used = np.unique(hull.simplices)
+    remap = {int(o): i for i, o in enumerate(used)}
+    verts = pts[used]
+    tris = [[remap[int(i)] for i in s] for s in hull.simplices]
+    return verts.tolist(), tris
+
+
+def rand_shape(rng, kind, spread):
+    t = tuple(rng.uniform(-spread, spread, 3))
+    q = quat_from_rpy(*rng.uniform(-math.pi, math.pi, 3))
+    if kind == "box":
+        return ShapeSpec.box(rng.uniform(0.03, 0.25, 3), t, q)
+    if kind == "ball":
+        return ShapeSpec.ball(rng.uniform(0.03, 0.2), t, q)
+    if kind == "cyl":
+        return ShapeSpec.cylinder(rng.uniform(0.02, 0.12), rng.uniform(0.05, 0.4), t, q)
+    v, tr = rand_convex_mesh(rng, rng.uniform(0.05, 0.25))
+    return ShapeSpec.mesh(v, tr, t, q)
+
+
+PAIRS = [("box", "box"), ("box", "ball"), ("ball", "box"), ("ball", "ball"), ("cyl", "box"), ("box", "cyl"),
+         ("cyl", "ball"), ("cyl", "cyl"), ("mesh", "box"), ("mesh", "mesh"), ("ball", "mesh")]
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("ka,kb", PAIRS)
+def test_random_pairs_match_oracle(ka, kb, prec):
+    rng = np.random.default_rng(1000 + PAIRS.index((ka, kb)))
+    n = 600 if "cyl" in (ka, kb) or "mesh" in (ka, kb) else 2000
+    hits = near = uncert = bad = 0
+    for _ in range(n):
+        a = rand_shape(rng, ka, 0.22)
+        b = rand_shape(rng, kb, 0.22)
+        d, lo = orc.distance_bounds(a, b, prec)
+        got = harness.pair_within(a, b, MARGIN, prec)
+        assert got in (0, 1), got
+        want = 1 if d < MARGIN else 0
+        hits += want
+        if got != want:
+            if abs(d - MARGIN) <= BAND[prec]:
+                near += 1
+            elif want == 0 and lo - BAND[prec] < MARGIN:
+                # the restated f32 GJK stopped (simplex degeneracy thresholds) before its own bounds
+                # separated d from the margin: true distance in [lo, d] straddles it
+                uncert += 1
+            else:
+                bad += 1
+                print("MISMATCH", ka, kb, prec, d, lo, got, a, b)
+    print(f"{ka}-{kb} f{prec}: n={n} hits={hits} in-band={near} oracle-uncertified={uncert} bad={bad}")
+    assert bad == 0
+    if prec == 64:
+        assert uncert == 0
+    assert 0.05 * n < hits < 0.98 * n  # the sample exercises both outcomes
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_near_margin_box_pairs(prec):
+    """Pairs placed deliberately close to the margin: face-face, edge-edge and vertex-vertex gaps."""
+    rng = np.random.default_rng(5)
+    bad = 0
+    for _ in range(400):
+        ha, hb = rng.uniform(0.05, 0.3, 3), rng.uniform(0.05, 0.3, 3)
+        sign = rng.choice([-1.0, 1.0], 3)
+        mode = rng.integers(1, 4)  # number of axes along which the boxes are separated
+        gap = MARGIN * rng.uniform(0.7, 1.3) / math.sqrt(mode)
+        off = np.zeros(3)
+        axes = rng.permutation(3)[:mode]
+        for ax in range(3):
+            if ax in axes:
+                off[ax] = sign[ax] * (ha[ax] + hb[ax] + gap)
+            else:
+                off[ax] = rng.uniform(-0.5, 0.5) * min(ha[ax], hb[ax])
+        a, b = ShapeSpec.box(ha), ShapeSpec.box(hb, tuple(off))
+        true_d = gap * math.sqrt(mode)
+        got = harness.pair_within(a, b, MARGIN, prec)
+        d = orc.distance(a, b, prec)
+        if abs(true_d - MARGIN) > BAND[prec]:
+            assert got == (1 if true_d < MARGIN else 0), (true_d, got)
+        if got != (1 if d < MARGIN else 0) and abs(d - MARGIN) > BAND[prec]:
+            bad += 1
+    assert bad == 0
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_hollow_mesh_rule(prec):
+    cyl = ShapeSpec.cylinder(0.5, 2.0)
+    assert harness.pair_within(cyl, ShapeSpec.ball(0.1), MARGIN, prec) == 0          # strictly inside: free
+    assert harness.pair_within(ShapeSpec.ball(0.1), cyl, MARGIN, prec) == 0
+    assert harness.pair_within(cyl, ShapeSpec.box((0.1, 0.1, 0.1), (0, 0, 0.8)), MARGIN, prec) == 0
+    assert harness.pair_within(cyl, ShapeSpec.box((0.1, 0.1, 0.1), (0, 0, 0.895)), MARGIN, prec) == 1  # 5 mm from the cap
+    assert harness.pair_within(cyl, ShapeSpec.ball(0.1, (0.45, 0, 0)), MARGIN, prec) == 1  # crosses the wall
+    assert harness.pair_within(ShapeSpec.cylinder(0.05, 0.1), ShapeSpec.box((1, 1, 1)), MARGIN, prec) == 1  # solid box
+    assert harness.pair_within(cyl, ShapeSpec.cylinder(0.05, 0.1), MARGIN, prec) == 0   # mesh inside mesh
+    assert harness.pair_within(ShapeSpec.cylinder(0.05, 0.1), cyl, MARGIN, prec) == 0
+
+
+def test_nonconvex_mesh_rejected():
+    # an open mesh (one face missing) and a non-convex closed one
+    v = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    open_tris = [(0, 1, 2), (0, 1, 3), (0, 2, 3)]
+    assert harness.pair_within(ShapeSpec.mesh(v, open_tris), ShapeSpec.ball(0.1, (5, 5, 5)), MARGIN, 64) == -5
