@@ -40,7 +40,15 @@ GD float t_copysign(float m, float s) { return copysignf(m, s); }
 GD double t_copysign(double m, double s) { return copysign(m, s); }
 GD float t_sqrt(float x) { return sqrtf(x); }
 GD double t_sqrt(double x) { return sqrt(x); }
-GD void t_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+// f32 joints take sin/cos through f64 and round once: the f32 reference (glibc/LLVM sinf, ~0.5 ulp)
+// and ocml's sincosf (~1-2 ulp) otherwise drift apart by a few 1e-7 over a 7-joint chain, which is
+// the whole 1e-6 pose budget.  7 f64 sincos per configuration are noise next to the pair tests.
+GD void t_sincos(float x, float* s, float* c) {
+  double sd, cd;
+  sincos((double)x, &sd, &cd);
+  *s = (float)sd;
+  *c = (float)cd;
+}
 GD void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 template <class T> GD T t_max(T a, T b) { return a > b ? a : b; }
 template <class T> GD T t_min(T a, T b) { return a < b ? a : b; }
