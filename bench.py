@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — collision-checked configs/sec on BASELINE.json's metric scene
+(7-DOF arm vs 256 obstacles; env + self + limit flags), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (gh_check_batch_dev) over one batch of
+synthetic joint configurations already resident in HBM; with N > 1 every rank
+checks its own shard of the batch (scene replicated per GPU, no data-path
+collective) and the per-config flag bytes are gathered over RCCL each step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from gear_amd import descriptors as D
+from gear_amd import engine
+from gear_amd import workloads as W
+
+VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops_per_config(w, counters):
+    """F = F_fk + pairs*F_cull + sat*F_sat + exact*F_gjk with the measured
+    per-config pair / SAT / exact-query counts of an instrumented run."""
+    nodes = w.chain.nodes
+    movable = sum(1 for n in nodes if n.is_movable)
+    fixed = len(nodes) - movable
+    L = w.robot_keep.desc.n_shapes
+    f_fk = 94 * movable + 61 * fixed + 61 * L
+    n = max(counters["configs"], 1)
+    pairs, sat, exact = counters["pairs"] / n, counters["sat_tests"] / n, counters["exact_tests"] / n
+    return f_fk + 11.0 * pairs + 220.0 * sat + 600.0 * exact, {
+        "pairs_per_config": pairs, "cull_survivors_per_config": counters["cull_pass"] / n,
+        "sat_per_config": sat, "exact_per_config": exact,
+        "exact_iters_per_query": counters["exact_iters"] / max(counters["exact_tests"], 1), "F_fk": f_fk}
+
+
+def device_configs(w, n, seed, dtype, device):
+    """generate_random_joint_positions_from_limits (src/funcs.rs:76-87) on the device: (max-min)*u + min."""
+    lo, hi = W.joint_limits(w.chain, w.using)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u = torch.rand((n, w.dof), generator=g, device=device, dtype=torch.float64)
+    lo_t = torch.tensor(lo, device=device, dtype=torch.float64)
+    hi_t = torch.tensor(hi, device=device, dtype=torch.float64)
+    return ((hi_t - lo_t) * u + lo_t).to(dtype).contiguous()
+
+
+def cpu_baseline(w, precision, seconds=12.0):
+    """The reference's CPU path as restated by oracle/ ("port"): is_feasible-style early exits and the
+    per-obstacle FK the reference does, (i) single-threaded (the reference is !Send) and (ii) one
+    independent chain per thread on the host cores available to this process."""
+    from oracle import binding as orc
+    ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, precision)
+    dtype = np.float32 if precision == 32 else np.float64
+    probe = w.configs(32, seed=999, dtype=dtype)
+    t0 = time.perf_counter()
+    ora.check(probe, faithful=True, redundant_fk=True, threads=1, want_band=False)
+    rate1 = len(probe) / max(time.perf_counter() - t0, 1e-9)
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    n1 = max(32, int(rate1 * seconds * 0.4))
+    q1 = w.configs(n1, seed=1000, dtype=dtype)
+    t0 = time.perf_counter()
+    ora.check(q1, faithful=True, redundant_fk=True, threads=1, want_band=False)
+    single = n1 / (time.perf_counter() - t0)
+    nm = max(64, int(single * cores * seconds * 0.6))
+    qm = w.configs(nm, seed=1001, dtype=dtype)
+    t0 = time.perf_counter()
+    ora.check(qm, faithful=True, redundant_fk=True, threads=cores, want_band=False)
+    multi = nm / (time.perf_counter() - t0)
+    return {"value": multi, "unit": "configs/s", "cores": cores, "kind": "port",
+            "single_thread_value": single,
+            "sample": f"{nm} configs on {cores} threads and {n1} configs on 1 thread of the same scene and "
+                      f"input distribution; C++ restatement of gear's path (oracle/), not the Rust crate"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1 << 22, help="configurations per GPU per step")
+    ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--obstacles", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    w = W.metric_workload(args.obstacles)
+    scene = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, args.precision, device=local_rank)
+    dtype = torch.float32 if args.precision == 32 else torch.float64
+    what = D.GH_CHECK_ENV | D.GH_CHECK_SELF
+    B = args.batch
+    q = device_configs(w, B, seed=1234 + rank, dtype=dtype, device=device)   # this rank's shard
+    flags = torch.zeros(B, dtype=torch.uint8, device=device)
+    gathered = torch.zeros(B * world, dtype=torch.uint8, device=device) if world > 1 else None
+    # a non-default torch stream: its handle is what the C ABI launches on, so torch.cuda.Event
+    # (HIP events on that same stream) brackets the kernel itself
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
+
+    # instrumented run (survivor fractions for the algorithmic-flop figure) on a 64k sample
+    ns = min(B, 1 << 16)
+    torch.cuda.synchronize()
+    counters = scene.check_batch_counted(q[:ns], flags[:ns], what)
+    flops_per_config, mix = algorithmic_flops_per_config(w, counters)
+
+    def step():
+        scene.check_batch_dev(q, flags, what, stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, flags)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        scene.check_batch_dev(q, flags, what, stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, flags)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # collision statistics (and a whole-job reduction when sharded)
+    stats = torch.stack([(flags & 1).ne(0).sum(), (flags & 2).ne(0).sum(), (flags & 4).ne(0).sum()]).to(torch.int64)
+    if world > 1:
+        dist.all_reduce(stats)
+    total_configs = B * world * args.steps
+    value = total_configs / elapsed
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        # bounded parity spot-check of the timed inputs against the CPU oracle
+        from oracle import binding as orc
+        from tests.parity import compare_flags
+        ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, args.precision)
+        k = 256
+        want, band = ora.check(q[:k].cpu().numpy(), what, threads=16)
+        rep = compare_flags(flags[:k].cpu().numpy(), want, band, args.precision)
+        parity = {kk: rep[kk] for kk in ("total", "mismatched", "in_band", "oracle_uncertified", "outside")}
+
+    if rank == 0:
+        achieved_tflops = flops_per_config * B / (kernel_ms * 1e-3) / 1e12
+        peak = VALU_PEAK_TFLOPS[args.precision]
+        bytes_per_config = w.dof * (4 if args.precision == 32 else 8) + 1
+        out = {
+            "metric": "collision-checked configs/sec (whole node), 7-DOF arm vs 256 obstacles",
+            "value": value, "unit": "configs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
+            "config": {"workload": w.name, "dof": w.dof, "nodes": len(w.chain.nodes),
+                       "robot_shapes": int(w.robot_keep.desc.n_shapes), "obstacles": int(w.obstacle_keep.desc.n_shapes),
+                       "self_pairs": int(w.robot_keep.desc.n_pairs), "margin": w.margin,
+                       "batch_per_gpu": B, "checks": "env+self+limit", "sharding": f"dp{world}, scene replicated",
+                       "collectives": "all_gather(flags) per step" if world > 1 else "none"},
+            "roofline": {
+                "bound": "valu", "kernel": "k_check", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved_tflops / peak, "traffic": None,
+                "kernel_ms": kernel_ms, "algorithmic_flops_per_config": flops_per_config, "mix": mix,
+                "hbm_algorithmic_GBps": bytes_per_config * B / (kernel_ms * 1e-3) / 1e9,
+                "hbm_peak_GBps": HBM_PEAK_GBS,
+                "note": "VALU-bound path (SURVEY 8d): the f32 vector peak equals the f32 MFMA peak; MFMA unused by design"},
+            "flag_rates": {"env": stats[0].item() / (B * world), "self": stats[1].item() / (B * world),
+                           "limit": stats[2].item() / (B * world)},
+            "parity_spot_check": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.precision)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
