@@ -352,40 +352,47 @@ GD bool inside_with_clearance(const ShapeRef<T>& P, const ShapeRef<T>& X, const 
 
 struct LaneCounters { unsigned cull_pass, sat_tests, exact_tests, exact_iters; };
 
-// distance(poseA, A, poseB, B) < margin, for a pair that survived the cull.
-template <class T, bool COUNT, class VP, class PP>
-GD bool pair_within(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, VP verts,
-                    PP planes, T margin, LaneCounters& lc) {
+enum : int { PR_FREE = 0, PR_HIT = 1, PR_EXACT = 2 };
+
+// Stage 1 of "distance(poseA, A, poseB, B) < margin" for a pair that survived the
+// cull: closed forms (ball pairs) and the separating-axis test (box pairs).
+// PR_EXACT = undecided here (a mesh is involved, or the boxes' best axis shows a
+// gap inside [0, margin)): stage 2 decides.
+template <class T, bool COUNT>
+GD int pair_stage1(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, T margin,
+                   LaneCounters& lc) {
+  if (A.kind == SK_MESH || B.kind == SK_MESH) return T(0) < margin ? PR_EXACT : PR_FREE;
   if (A.kind == SK_BALL && B.kind == SK_BALL) {
     // distance_ball_ball, verbatim semantics
     V3<T> d = wa.t - wb.t;
     T d2 = dot(d, d), sum = A.half.x + B.half.x;
     T dist = d2 <= sum * sum ? T(0) : t_sqrt(d2) - sum;
-    return dist < margin;
+    return dist < margin ? PR_HIT : PR_FREE;
   }
   Rel<T> rel = make_rel(wa, wb);
-  if (A.kind != SK_MESH && B.kind != SK_MESH) {
-    if (A.kind == SK_BOX && B.kind == SK_BOX) {
-      if (COUNT) lc.sat_tests++;
-      int r = sat_box_box(A.half, B.half, rel, margin);
-      if (r != 2) return r == 1 && T(0) < margin;
-      if (COUNT) lc.exact_tests++;
-      int it;
-      bool hit = gjk_within(A, B, rel, verts, margin, it);
-      if (COUNT) lc.exact_iters += it + 1;
-      return hit;
-    }
-    // ball vs box: point-to-box distance in the box's frame
-    V3<T> p, h;
-    T r;
-    if (A.kind == SK_BOX) { p = rel.t; h = A.half; r = B.half.x; }
-    else { p = -rel_tmul(rel, rel.t); h = B.half; r = A.half.x; }
-    V3<T> e{t_max(t_abs(p.x) - h.x, T(0)), t_max(t_abs(p.y) - h.y, T(0)), t_max(t_abs(p.z) - h.z, T(0))};
-    T dist = t_max(t_sqrt(dot(e, e)) - r, T(0));
-    return dist < margin;
+  if (A.kind == SK_BOX && B.kind == SK_BOX) {
+    if (COUNT) lc.sat_tests++;
+    int r = sat_box_box(A.half, B.half, rel, margin);
+    if (r == 2) return PR_EXACT;
+    return (r == 1 && T(0) < margin) ? PR_HIT : PR_FREE;
   }
+  // ball vs box: point-to-box distance in the box's frame
+  V3<T> p, h;
+  T r;
+  if (A.kind == SK_BOX) { p = rel.t; h = A.half; r = B.half.x; }
+  else { p = -rel_tmul(rel, rel.t); h = B.half; r = A.half.x; }
+  V3<T> e{t_max(t_abs(p.x) - h.x, T(0)), t_max(t_abs(p.y) - h.y, T(0)), t_max(t_abs(p.z) - h.z, T(0))};
+  T dist = t_max(t_sqrt(dot(e, e)) - r, T(0));
+  return dist < margin ? PR_HIT : PR_FREE;
+}
+
+// Stage 2: GJK margin query on the convex cores (ball radii folded into the
+// margin) plus the hollow-mesh rule.
+template <class T, bool COUNT, class VP, class PP>
+GD bool pair_stage2(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, VP verts,
+                    PP planes, T margin, LaneCounters& lc) {
   if (!(T(0) < margin)) return false;
-  // a convex mesh is involved: margin query on the cores, ball radii folded into the margin
+  Rel<T> rel = make_rel(wa, wb);
   T m = margin + (A.kind == SK_BALL ? A.half.x : T(0)) + (B.kind == SK_BALL ? B.half.x : T(0));
   if (COUNT) lc.exact_tests++;
   int it;
@@ -395,6 +402,15 @@ GD bool pair_within(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& 
   if (A.kind == SK_MESH && inside_with_clearance(A, B, rel, true, verts, planes, margin)) return false;
   if (B.kind == SK_MESH && inside_with_clearance(B, A, rel, false, verts, planes, margin)) return false;
   return true;
+}
+
+// both stages back to back (diagnostic kernels, host harness)
+template <class T, bool COUNT, class VP, class PP>
+GD bool pair_within(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, VP verts,
+                    PP planes, T margin, LaneCounters& lc) {
+  int r = pair_stage1<T, COUNT>(A, wa, B, wb, margin, lc);
+  if (r != PR_EXACT) return r == PR_HIT;
+  return pair_stage2<T, COUNT>(A, wa, B, wb, verts, planes, margin, lc);
 }
 
 }  // namespace gear_hip

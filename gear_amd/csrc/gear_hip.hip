@@ -36,7 +36,7 @@ int fail(int code, const std::string& msg) {
 
 // LDS budget per wavefront-workgroup for the per-lane pose columns; beyond it the
 // columns move to a global workspace (chunked launches).
-constexpr size_t kLdsBudget = 40 * 1024;
+constexpr size_t kLdsBudget = 36 * 1024;
 constexpr size_t kChunk = size_t(1) << 22;  // configurations per launch when a global store is in use
 
 struct DevBuf {
@@ -106,7 +106,12 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.rshapes, &S.rshapes))) return rc;
   if ((rc = upload(sc, H.oshapes, &S.oshapes))) return rc;
   if ((rc = upload(sc, H.ocull, &S.ocull))) return rc;
+  if ((rc = upload(sc, H.ocull8, &S.ocull8))) return rc;
+  S.n_obs_pad = (int)(H.ocull8.size() / 8);
   if ((rc = upload(sc, H.pairs, &S.pairs))) return rc;
+  if ((rc = upload(sc, H.spairs, &S.spairs))) return rc;
+  if ((rc = upload(sc, H.spair_r, &S.spair_r))) return rc;
+  S.n_spairs = (int)H.spair_r.size();
   if ((rc = upload(sc, H.verts, &S.verts))) return rc;
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
   sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
@@ -153,28 +158,28 @@ int for_chunks(gh_scene* sc, size_t n, const StorePlan& plan, F&& launch) {
 
 unsigned grid_for(size_t n) { return (unsigned)((n + kWave - 1) / kWave); }
 
+template <class T>
+void launch_check(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, uint8_t* flags,
+                  hipStream_t st, bool counted, const StorePlan& plan, void* gs, size_t gstride) {
+  const size_t lds = plan.lds_bytes + kQueueBytes;
+  const dim3 grid(grid_for(cnt)), block(kWave);
+  if (plan.global) {
+    if (counted) hipLaunchKernelGGL((k_check<T, true, true>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
+    else hipLaunchKernelGGL((k_check<T, false, true>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
+  } else {
+    if (counted) hipLaunchKernelGGL((k_check<T, true, false>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
+    else hipLaunchKernelGGL((k_check<T, false, false>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
+  }
+}
+
 int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted) {
   if (!(sc->margin > 0)) what = 0;  // distance >= 0 is never < a non-positive margin: only limits can fail
-  const bool need_shapes = (what & GH_CHECK_SELF) && sc->P > 0;
-  StorePlan plan = plan_store(sc, need_shapes);
+  StorePlan plan = plan_store(sc, true);  // the batched kernel keeps every shape pose in the lane's column
   return for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
-    if (sc->precision == 32) {
-      const float* qq = (const float*)q + off * sc->D;
-      if (counted)
-        hipLaunchKernelGGL((k_check<float, true>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s32, qq,
-                           cnt, what, flags + off, sc->counters, (float*)gs, gstride);
-      else
-        hipLaunchKernelGGL((k_check<float, false>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s32, qq,
-                           cnt, what, flags + off, sc->counters, (float*)gs, gstride);
-    } else {
-      const double* qq = (const double*)q + off * sc->D;
-      if (counted)
-        hipLaunchKernelGGL((k_check<double, true>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s64, qq,
-                           cnt, what, flags + off, sc->counters, (double*)gs, gstride);
-      else
-        hipLaunchKernelGGL((k_check<double, false>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, st, sc->s64, qq,
-                           cnt, what, flags + off, sc->counters, (double*)gs, gstride);
-    }
+    if (sc->precision == 32)
+      launch_check<float>(sc, sc->s32, (const float*)q + off * sc->D, cnt, what, flags + off, st, counted, plan, gs, gstride);
+    else
+      launch_check<double>(sc, sc->s64, (const double*)q + off * sc->D, cnt, what, flags + off, st, counted, plan, gs, gstride);
   });
 }
 

@@ -35,12 +35,16 @@ template <class T> struct Views {
   const GEAR_CAS ShapeDev<T>* rshapes;
   const GEAR_CAS ShapeDev<T>* oshapes;
   const GEAR_CAS T* ocull;
+  const GEAR_CAS T* ocull8;
   const GEAR_CAS PairDev* pairs;
+  const GEAR_CAS int32_t* spairs;
+  const GEAR_CAS T* spair_r;
   const GEAR_CAS T* verts;
   const GEAR_CAS T* planes;
   __device__ explicit Views(const SceneDev<T>& S)
       : nodes(to_cas(S.nodes)), limits(to_cas(S.limits)), rshapes(to_cas(S.rshapes)), oshapes(to_cas(S.oshapes)),
-        ocull(to_cas(S.ocull)), pairs(to_cas(S.pairs)), verts(to_cas(S.verts)), planes(to_cas(S.planes)) {}
+        ocull(to_cas(S.ocull)), ocull8(to_cas(S.ocull8)), pairs(to_cas(S.pairs)), spairs(to_cas(S.spairs)),
+        spair_r(to_cas(S.spair_r)), verts(to_cas(S.verts)), planes(to_cas(S.planes)) {}
 };
 
 template <class T, class SP> GD ShapeRef<T> shape_ref(SP sh) {
@@ -119,86 +123,260 @@ template <class T> __device__ PoseStore<T> make_store(T* gstore, size_t gstride,
 }
 
 // ---------------------------------------------------------------------------
-// k_check
+// k_check — the hot kernel
+//
+// Per wavefront (64 configurations):
+//   1. limits + FK walk; every robot shape's world pose goes to the lane's pose
+//      column (LDS, or a global workspace for very large robots).
+//   2. cull sweep: 32 (shape, obstacle) pairs at a time, five VALU ops per pair
+//      with the obstacle record in SGPRs; the sign bit of d^2 - R^2 is shifted
+//      into a per-lane survivor mask (v_alignbit), so there is no branch and no
+//      compare in the sweep.  Self pairs are swept the same way.
+//   3. survivors are rare (a few per configuration) and land on different lanes
+//      at different times, so running their narrow phase in place would leave
+//      63 of 64 lanes idle.  Instead every survivor is pushed to a wave-shared
+//      queue in LDS (ballot + mbcnt compaction) and the queue is drained 64
+//      items at a time, one item per lane: closed forms / SAT first; what those
+//      cannot decide is re-queued and drained by the GJK margin query.  Hits
+//      are OR-ed into a per-wave bit mask in LDS indexed by the owning lane.
 // ---------------------------------------------------------------------------
-template <class T, bool COUNT>
+constexpr int kQCap = 448;  // stage-1 queue entries per wave
+constexpr int kGCap = 192;  // stage-2 (exact) queue entries per wave
+constexpr size_t kQueueBytes = (kQCap + kGCap + 4) * 4;
+
+GD float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+GD double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+GD unsigned sign_bits(float t) { return __float_as_uint(t); }
+GD unsigned sign_bits(double t) { return (unsigned)__double2hiint(t); }
+
+template <class T> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 1.2e-7f; };
+template <> struct Eps<double> { static constexpr double v = 2.3e-16; };
+
+template <class T> struct WaveStore {
+  T* base;
+  size_t stride, col0;  // column of lane l = col0 + l
+  GD void put(int slot, int lane, const Pose<T>& p) const {
+    T* b = base + (size_t)slot * 7 * stride + col0 + lane;
+    b[0] = p.t.x; b[stride] = p.t.y; b[2 * stride] = p.t.z;
+    b[3 * stride] = p.r.i; b[4 * stride] = p.r.j; b[5 * stride] = p.r.k; b[6 * stride] = p.r.w;
+  }
+  GD Pose<T> get(int slot, int lane) const {
+    const T* b = base + (size_t)slot * 7 * stride + col0 + lane;
+    return {{b[0], b[stride], b[2 * stride]}, {b[3 * stride], b[4 * stride], b[5 * stride], b[6 * stride]}};
+  }
+  GD V3<T> centre(int slot, int lane) const {
+    const T* b = base + (size_t)slot * 7 * stride + col0 + lane;
+    return {b[0], b[stride], b[2 * stride]};
+  }
+};
+
+template <bool GSTORE> __device__ __forceinline__ void wave_sync() {
+  // lanes of one wave exchange data through LDS (and, with a global pose store, through memory)
+  if (GSTORE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class T, bool COUNT, bool GSTORE>
 __global__ void __launch_bounds__(kWave)
 k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t* __restrict__ flags,
         CountersDev* __restrict__ ctr, T* gstore, size_t gstride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
-  size_t i = (size_t)blockIdx.x * kWave + threadIdx.x;
+  const int lane = threadIdx.x;
+  size_t i = (size_t)blockIdx.x * kWave + lane;
   const bool live = i < n;
-  if (!live) i = n - 1;  // keep the lane on valid data; it stores nothing
+  if (!live) i = n - 1;  // keep the lane on valid data; it pushes and stores nothing
   const T* qrow = q + i * (size_t)S.n_cols;
-  const PoseStore<T> st = make_store<T>(gstore, gstride, i);
+  const int pose_slots = S.n_slots + S.n_shapes;
+  WaveStore<T> st;
+  unsigned* q1;
+  if (GSTORE) {
+    st = {gstore, gstride, (size_t)blockIdx.x * kWave};
+    q1 = reinterpret_cast<unsigned*>(gear_lds);
+  } else {
+    st = {reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)0};
+    q1 = reinterpret_cast<unsigned*>(gear_lds + (size_t)pose_slots * 7 * kWave * sizeof(T));
+  }
+  unsigned* q2 = q1 + kQCap;
+  unsigned* hits = q2 + kGCap;  // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
+  if (lane < 4) hits[lane] = 0;
+
   const bool do_env = (what & 1u) && S.n_obs > 0;
-  const bool do_self = (what & 2u) && S.n_pairs > 0;
+  const bool do_self = (what & 2u) && S.n_spairs > 0;
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   unsigned long long npairs = 0;
 
   const bool ok = limits_ok(S, V, qrow);
-  bool env_hit = false, self_hit = false;
 
-  Pose<T> cur{{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
-  for (int k = 0; k < S.n_nodes; k++) {
-    node_world(V, k, qrow, st, cur);
-    const int sb = V.nodes[k].shape_begin, se = V.nodes[k].shape_end;
-    for (int s = sb; s < se; s++) {
-      const GEAR_CAS ShapeDev<T>* sh = V.rshapes + s;
-      const Pose<T> ws = pose_mul(cur, shape_pose<T>(sh));
-      if (do_self) st.put(S.n_slots + s, ws);
-      if (!do_env) continue;
-      const V3<T> c = bound_centre(sh, ws);
-      const T br = sh->br;
-      const ShapeRef<T> A = shape_ref<T>(sh);
-      for (int o = 0; o < S.n_obs; o++) {
-        // bounding-sphere cull; ocull.w already holds (obstacle radius + margin) * (1 + slack)
-        T dx = c.x - V.ocull[4 * o], dy = c.y - V.ocull[4 * o + 1], dz = c.z - V.ocull[4 * o + 2];
-        T rr = br + V.ocull[4 * o + 3];
-        bool near = dx * dx + dy * dy + dz * dz < rr * rr;
-        if (COUNT) npairs++;
-        if (near && !env_hit) {
-          if (COUNT) lc.cull_pass++;
-          const GEAR_CAS ShapeDev<T>* ob = V.oshapes + o;
-          if (pair_within<T, COUNT>(A, ws, shape_ref<T>(ob), shape_pose<T>(ob), V.verts, V.planes, margin, lc))
-            env_hit = true;
-        }
-      }
+  // ---- 1. FK walk -----------------------------------------------------------
+  {
+    PoseStore<T> ps{st.base, st.stride, st.col0 + lane};
+    Pose<T> cur{{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
+    for (int k = 0; k < S.n_nodes; k++) {
+      node_world(V, k, qrow, ps, cur);
+      for (int s = V.nodes[k].shape_begin; s < V.nodes[k].shape_end; s++)
+        ps.put(S.n_slots + s, pose_mul(cur, shape_pose<T>(V.rshapes + s)));
     }
   }
+  wave_sync<GSTORE>();
 
-  if (do_self) {
-    for (int p = 0; p < S.n_pairs; p++) {
-      const PairDev pr{V.pairs[p].s1_begin, V.pairs[p].s1_end, V.pairs[p].s2_begin, V.pairs[p].s2_end};
-      for (int s1 = pr.s1_begin; s1 < pr.s1_end; s1++) {
-        const GEAR_CAS ShapeDev<T>* h1 = V.rshapes + s1;
-        const Pose<T> w1 = st.get(S.n_slots + s1);
-        const V3<T> c1 = bound_centre(h1, w1);
-        const ShapeRef<T> A = shape_ref<T>(h1);
-        for (int s2 = pr.s2_begin; s2 < pr.s2_end; s2++) {
-          const GEAR_CAS ShapeDev<T>* h2 = V.rshapes + s2;
-          const Pose<T> w2 = st.get(S.n_slots + s2);
-          const V3<T> d = c1 - bound_centre(h2, w2);
-          T rr = (h1->br + h2->br + margin) * (T(1) + T(1e-4));
-          if (COUNT) npairs++;
-          if (dot(d, d) < rr * rr && !self_hit) {
-            if (COUNT) lc.cull_pass++;
-            if (pair_within<T, COUNT>(A, w1, shape_ref<T>(h2), w2, V.verts, V.planes, margin, lc)) self_hit = true;
+  // ---- 2 + 3. cull sweep feeding the survivor queues -----------------------
+  const int env_groups = do_env ? S.n_shapes * (S.n_obs_pad / 32) : 0;
+  const int self_groups = do_self ? (S.n_spairs + 31) / 32 : 0;
+  const int groups = env_groups + self_groups;
+  const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
+  bool env_done = false, self_done = false;
+  int qn = 0, gn = 0;  // wave-uniform queue fills
+  int s = 0, o0 = 0;
+  V3<T> c{T(0), T(0), T(0)};
+  T a0 = T(0), rho = T(0);
+
+  for (int g = 0; g < groups; g++) {
+    unsigned m = 0;
+    unsigned item_base;
+    const bool is_env = g < env_groups;
+    if (is_env) {
+      if (o0 == 0) {
+        c = st.centre(S.n_slots + s, lane);
+        rho = V.rshapes[s].br;
+        asm volatile("" : "+v"(rho));  // keep the radius in a VGPR: the obstacle record supplies the SGPR operand
+        T cc = dot(c, c), r2 = rho * rho;
+        a0 = (cc - r2) - T(16) * Eps<T>::v * (cc + r2);
+      }
+      const GEAR_CAS T* rec = V.ocull8 + (size_t)8 * o0;
+#pragma unroll
+      for (int k = 0; k < 32; k++) {
+        T t = a0 + rec[8 * k + 4];
+        t = t_fma(rec[8 * k + 0], c.x, t);
+        t = t_fma(rec[8 * k + 1], c.y, t);
+        t = t_fma(rec[8 * k + 2], c.z, t);
+        t = t_fma(rec[8 * k + 3], rho, t);
+        m = __builtin_amdgcn_alignbit(m, sign_bits(t), 31);  // m = (m << 1) | (t < 0)
+      }
+      if (COUNT) npairs += (unsigned)min(32, S.n_obs - o0 > 0 ? S.n_obs - o0 : 0);
+      item_base = ((unsigned)o0 << 16) | ((unsigned)s << 6) | (unsigned)lane;
+      if (env_done) m = 0;
+      o0 += 32;
+      if (o0 >= S.n_obs_pad) { o0 = 0; s++; }
+    } else {
+      const int p0 = (g - env_groups) * 32;
+      const int cnt = min(32, S.n_spairs - p0);
+      for (int k = 0; k < 32; k++) {
+        unsigned bit = 0;
+        if (k < cnt) {
+          const int s1 = V.spairs[4 * (p0 + k)], s2 = V.spairs[4 * (p0 + k) + 1];
+          V3<T> d = st.centre(S.n_slots + s1, lane) - st.centre(S.n_slots + s2, lane);
+          T rr = V.spair_r[p0 + k];
+          bit = dot(d, d) < rr * rr ? 1u : 0u;
+        }
+        m = (m << 1) | bit;
+      }
+      if (COUNT) npairs += (unsigned)cnt;
+      item_base = 0x80000000u | ((unsigned)p0 << 6) | (unsigned)lane;
+      if (self_done) m = 0;
+    }
+    if (!push_ok) m = 0;
+    if (COUNT) lc.cull_pass += __popc(m);
+
+    const bool last_group = g == groups - 1;
+    for (;;) {
+      // push one survivor per lane per round while the queue has room for a full round
+      while (qn + kWave <= kQCap) {
+        const bool has = m != 0;
+        const unsigned long long b = __ballot(has);
+        if (b == 0) break;
+        if (has) {
+          const int z = __clz(m);  // bit 31 - z  <->  k = z within the group
+          m &= ~(0x80000000u >> z);
+          const unsigned it = is_env ? item_base + ((unsigned)z << 16) : item_base + ((unsigned)z << 6);
+          q1[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = it;
+        }
+        qn += __popcll(b);
+      }
+      const bool more = __ballot(m != 0) != 0;
+      if (!more && !(last_group && (qn > 0 || gn > 0))) break;
+      const bool final = last_group && !more;  // last drain of the wave: empty both queues
+
+      // ---- drain: the single narrow-phase site -----------------------------
+      wave_sync<GSTORE>();
+      for (int base = 0; base < qn || (final && base == 0); base += kWave) {
+        const int j = base + lane;
+        bool valid = j < qn;
+        const unsigned it = valid ? q1[j] : 0u;
+        const int ln = it & 63;
+        const bool sf = (it >> 31) != 0;
+        int sa, sbx;
+        if (sf) { const int pi = (it >> 6) & 0x1ffffff; sa = V.spairs[4 * pi]; sbx = V.spairs[4 * pi + 1]; }
+        else { sa = (it >> 6) & 1023; sbx = (it >> 16) & 32767; }
+        int r = PR_FREE;
+        if (valid) {
+          const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
+          valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
+        }
+        if (valid) {
+          const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa);
+          const Pose<T> wa = st.get(S.n_slots + sa, ln);
+          ShapeRef<T> B;
+          Pose<T> wb;
+          if (sf) { B = shape_ref<T>(V.rshapes + sbx); wb = st.get(S.n_slots + sbx, ln); }
+          else { B = shape_ref<T>(V.oshapes + sbx); wb = shape_pose<T>(V.oshapes + sbx); }
+          r = pair_stage1<T, COUNT>(A, wa, B, wb, margin, lc);
+          if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
+        }
+        const bool ex = r == PR_EXACT;
+        const unsigned long long eb = __ballot(ex);
+        if (ex) q2[gn + __builtin_amdgcn_mbcnt_hi((unsigned)(eb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eb, 0u))] = it;
+        gn += __popcll(eb);
+        const bool final_drain = final && base + kWave >= qn;
+        while (gn >= kWave || (final_drain && gn > 0)) {
+          wave_sync<GSTORE>();
+          const int take = gn >= kWave ? kWave : gn;
+          const int g0 = gn - take;
+          bool v2 = lane < take;
+          const unsigned it2 = v2 ? q2[g0 + lane] : 0u;
+          const int ln2 = it2 & 63;
+          const bool sf2 = (it2 >> 31) != 0;
+          int sa2, sb2;
+          if (sf2) { const int pi = (it2 >> 6) & 0x1ffffff; sa2 = V.spairs[4 * pi]; sb2 = V.spairs[4 * pi + 1]; }
+          else { sa2 = (it2 >> 6) & 1023; sb2 = (it2 >> 16) & 32767; }
+          if (v2) {
+            const unsigned hw = hits[(sf2 ? 2 : 0) + (ln2 >> 5)];
+            v2 = ((hw >> (ln2 & 31)) & 1u) == 0;
           }
+          if (v2) {
+            const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa2);
+            const Pose<T> wa = st.get(S.n_slots + sa2, ln2);
+            ShapeRef<T> B;
+            Pose<T> wb;
+            if (sf2) { B = shape_ref<T>(V.rshapes + sb2); wb = st.get(S.n_slots + sb2, ln2); }
+            else { B = shape_ref<T>(V.oshapes + sb2); wb = shape_pose<T>(V.oshapes + sb2); }
+            if (pair_stage2<T, COUNT>(A, wa, B, wb, V.verts, V.planes, margin, lc))
+              atomicOr(&hits[(sf2 ? 2 : 0) + (ln2 >> 5)], 1u << (ln2 & 31));
+          }
+          gn = g0;
+          wave_sync<GSTORE>();
         }
       }
+      qn = 0;
+      wave_sync<GSTORE>();
+      env_done = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
+      self_done = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
+      if (is_env ? env_done : self_done) m = 0;
+      if (!more) break;
     }
   }
 
-  if (live) {
-    uint8_t f = ok ? (uint8_t)((env_hit ? 1 : 0) | (self_hit ? 2 : 0)) : (uint8_t)4;
-    flags[i] = f;
-  }
+  wave_sync<GSTORE>();
+  const bool env_hit = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
+  const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
+  if (live) flags[i] = ok ? (uint8_t)((env_hit ? 1 : 0) | (self_hit ? 2 : 0)) : (uint8_t)4;
   if (COUNT) {
-    if (!live) { lc = {0, 0, 0, 0}; npairs = 0; }
+    // counters live on whichever lane ran the test; only their sums are meaningful
     atomicAdd(&ctr->configs, live ? 1ull : 0ull);
-    atomicAdd(&ctr->pairs, npairs);
+    atomicAdd(&ctr->pairs, live ? npairs : 0ull);
     atomicAdd(&ctr->cull_pass, (unsigned long long)lc.cull_pass);
     atomicAdd(&ctr->sat_tests, (unsigned long long)lc.sat_tests);
     atomicAdd(&ctr->exact_tests, (unsigned long long)lc.exact_tests);

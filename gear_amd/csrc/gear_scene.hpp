@@ -25,8 +25,10 @@ struct HostTables {
   std::vector<NodeDev<T>> nodes;
   std::vector<LimitDev<T>> limits;
   std::vector<ShapeDev<T>> rshapes, oshapes;
-  std::vector<T> ocull;
+  std::vector<T> ocull, ocull8;
   std::vector<PairDev> pairs;
+  std::vector<int32_t> spairs;  // flattened self shape pairs: [n][4] = s1, s2, node-pair index, 0
+  std::vector<T> spair_r;       // [n] bounding radii sum + margin, inflated
   std::vector<T> verts, planes;
   int n_slots = 0;
   T margin = 0;
@@ -177,10 +179,25 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
         for (int k = 0; k < 3; k++) dd += (v[3 * i + k] - c[k]) * (v[3 * i + k] - c[k]);
         r2 = std::max(r2, dd);
       }
-      for (int k = 0; k < 3; k++) s.bc[k] = T(c[k]);
+      // re-centre the mesh on its bounding-sphere centre and fold the shift into the shape's pose
+      // (t += R(q) c), so that for every shape kind the bounding sphere sits at the pose translation
+      {
+        double q[4] = {d.q[0], d.q[1], d.q[2], d.q[3]};
+        double tx = 2 * (q[1] * c[2] - q[2] * c[1]), ty = 2 * (q[2] * c[0] - q[0] * c[2]), tz = 2 * (q[0] * c[1] - q[1] * c[0]);
+        double rc[3] = {c[0] + q[3] * tx + (q[1] * tz - q[2] * ty), c[1] + q[3] * ty + (q[2] * tx - q[0] * tz),
+                        c[2] + q[3] * tz + (q[0] * ty - q[1] * tx)};
+        for (int k = 0; k < 3; k++) s.lt[k] = T(d.t[k] + rc[k]);
+      }
+      for (int k = 0; k < 3; k++) s.bc[k] = T(0);
       s.br = T(std::sqrt(r2) * (1.0 + 1e-6));
-      for (double x : v) H.verts.push_back(T(x));
-      for (double x : planes) H.planes.push_back(T(x));
+      for (size_t i = 0; i < v.size(); i++) H.verts.push_back(T(v[i] - c[i % 3]));
+      for (size_t pl = 0; pl < planes.size() / 4; pl++) {
+        double off = planes[4 * pl + 3] - (planes[4 * pl] * c[0] + planes[4 * pl + 1] * c[1] + planes[4 * pl + 2] * c[2]);
+        H.planes.push_back(T(planes[4 * pl]));
+        H.planes.push_back(T(planes[4 * pl + 1]));
+        H.planes.push_back(T(planes[4 * pl + 2]));
+        H.planes.push_back(T(off));
+      }
       break;
     }
     default:
@@ -201,6 +218,8 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
   if (r.n_shapes < 0 || (r.n_shapes > 0 && !r.shapes)) return bad("robot shapes missing");
   if (o.n_shapes < 0 || (o.n_shapes > 0 && !o.shapes)) return bad("obstacle shapes missing");
   if (r.n_pairs < 0 || (r.n_pairs > 0 && !r.pairs)) return bad("pairs missing");
+  if (r.n_shapes > 1023) { err = {GH_ERR_TOO_LARGE, "at most 1023 robot collision shapes"}; return false; }
+  if (o.n_shapes > 32767) { err = {GH_ERR_TOO_LARGE, "at most 32767 obstacle shapes"}; return false; }
   const int N = r.n_nodes;
   H.margin = T(margin);
   H.nodes.assign(N, NodeDev<T>{});
@@ -293,6 +312,18 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
     H.ocull.push_back(T((double)sd.lt[2] + cz));
     double rr = (double)sd.br + std::max(margin, 0.0);
     H.ocull.push_back(T(rr + 1e-4 * (rr + (double)br_max) + 1e-9));
+    // batched-kernel record; tau absorbs the rounding of the expanded form so that the cull stays
+    // conservative (a pair within reach is never dropped)
+    const double eps = sizeof(T) == 4 ? 1.2e-7 : 2.3e-16;
+    double ox = (double)sd.lt[0] + cx, oy = (double)sd.lt[1] + cy, oz = (double)sd.lt[2] + cz;
+    double R = rr * (1.0 + 1e-5) + 1e-9, c2 = ox * ox + oy * oy + oz * oz;
+    double rec[8] = {-2 * ox, -2 * oy, -2 * oz, -2 * R, c2 - R * R - 16 * eps * (c2 + R * R), 0, 0, 0};
+    for (double x : rec) H.ocull8.push_back(T(x));
+  }
+  while ((H.ocull8.size() / 8) % 32 != 0) {
+    // far dummy: k is huge and positive, the test value can never go negative
+    const double rec[8] = {0, 0, 0, 0, 1e30, 0, 0, 0};
+    for (double x : rec) H.ocull8.push_back(T(x));
   }
   // self pairs -> shape ranges; a pair whose joint has no model never yields
   // (collision_checker.rs:150-159)
@@ -301,6 +332,12 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
     if (a < 0 || a >= N || b < 0 || b >= N) return bad("self pair node out of range");
     PairDev pd{H.nodes[a].shape_begin, H.nodes[a].shape_end, H.nodes[b].shape_begin, H.nodes[b].shape_end};
     H.pairs.push_back(pd);  // an empty range simply never hits; pair indices stay the caller's
+    for (int s1 = pd.s1_begin; s1 < pd.s1_end; s1++)
+      for (int s2 = pd.s2_begin; s2 < pd.s2_end; s2++) {
+        H.spairs.insert(H.spairs.end(), {s1, s2, p, 0});
+        double rr = (double)H.rshapes[s1].br + (double)H.rshapes[s2].br + std::max(margin, 0.0);
+        H.spair_r.push_back(T(rr * (1.0 + 1e-4) + 1e-9));
+      }
   }
   return true;
 }

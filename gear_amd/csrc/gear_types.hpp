@@ -76,7 +76,15 @@ struct SceneDev {
   const ShapeDev<T>* rshapes;
   const ShapeDev<T>* oshapes;
   const T* ocull;  // [n_obs][4]: world bounding sphere cx,cy,cz and radius + margin (pre-inflated)
+  // [n_obs_pad][8] cull records for the batched kernel, n_obs_pad a multiple of 32 (tail = far dummies):
+  //   -2cx, -2cy, -2cz, -2R, |c|^2 - R^2 - tau, 0, 0, 0     with R = obstacle radius + margin (inflated)
+  // so that  d^2 - (rho + R)^2 = (|p|^2 - rho^2) + k + p . (-2c) + rho * (-2R)  costs five VALU ops per pair.
+  const T* ocull8;
+  int32_t n_obs_pad, pad2;
   const PairDev* pairs;
+  const int32_t* spairs;  // [n_spairs][4]: s1, s2, node-pair index, 0
+  const T* spair_r;       // [n_spairs]: inflated bounding-radius sum + margin
+  int32_t n_spairs, pad3;
   const T* verts;   // [..][3]
   const T* planes;  // [..][4]
 };
