@@ -361,7 +361,16 @@ enum : int { PR_FREE = 0, PR_HIT = 1, PR_EXACT = 2 };
 template <class T, bool COUNT>
 GD int pair_stage1(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, T margin,
                    LaneCounters& lc) {
-  if (A.kind == SK_MESH || B.kind == SK_MESH) return T(0) < margin ? PR_EXACT : PR_FREE;
+  if (A.kind == SK_MESH || B.kind == SK_MESH) {
+    // a mesh carries the half extents of its local bounding box in `half` (a ball: the cube around it):
+    // boxes that are >= margin apart prove the shapes are; anything closer goes to the exact stage
+    if (!(T(0) < margin)) return PR_FREE;
+    Rel<T> rel = make_rel(wa, wb);
+    V3<T> ha = A.kind == SK_BALL ? V3<T>{A.half.x, A.half.x, A.half.x} : A.half;
+    V3<T> hb = B.kind == SK_BALL ? V3<T>{B.half.x, B.half.x, B.half.x} : B.half;
+    if (COUNT) lc.sat_tests++;
+    return sat_box_box(ha, hb, rel, margin) == 0 ? PR_FREE : PR_EXACT;
+  }
   if (A.kind == SK_BALL && B.kind == SK_BALL) {
     // distance_ball_ball, verbatim semantics
     V3<T> d = wa.t - wb.t;

@@ -107,7 +107,7 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.oshapes, &S.oshapes))) return rc;
   if ((rc = upload(sc, H.ocull, &S.ocull))) return rc;
   if ((rc = upload(sc, H.ocull8, &S.ocull8))) return rc;
-  S.n_obs_pad = (int)(H.ocull8.size() / 8);
+  S.n_obs_pad = (int)(H.ocull8.size() / 5);
   if ((rc = upload(sc, H.pairs, &S.pairs))) return rc;
   if ((rc = upload(sc, H.spairs, &S.spairs))) return rc;
   if ((rc = upload(sc, H.spair_r, &S.spair_r))) return rc;

@@ -153,6 +153,27 @@ template <class T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.2e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.3e-16; };
 
+// 8 obstacles' cull records (40 scalars, wave-uniform -> SGPRs)
+template <class T> struct CullBlock {
+  T v[40];
+  template <class P> GD void load(P p) {
+#pragma unroll
+    for (int i = 0; i < 40; i++) v[i] = p[i];
+  }
+  GD unsigned sweep(unsigned m, V3<T> c, T rho, T a0) const {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      T t = a0 + v[32 + k];
+      t = t_fma(v[k], c.x, t);
+      t = t_fma(v[8 + k], c.y, t);
+      t = t_fma(v[16 + k], c.z, t);
+      t = t_fma(v[24 + k], rho, t);
+      m = __builtin_amdgcn_alignbit(m, sign_bits(t), 31);  // m = (m << 1) | (t < 0)
+    }
+    return m;
+  }
+};
+
 template <class T> struct WaveStore {
   T* base;
   size_t stride, col0;  // column of lane l = col0 + l
@@ -205,6 +226,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
 
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
+  const bool dbg_no_exact = (what & 0x100u) != 0, dbg_no_drain = (what & 0x200u) != 0;  // profiling ablations
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   unsigned long long npairs = 0;
@@ -246,16 +268,18 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
         T cc = dot(c, c), r2 = rho * rho;
         a0 = (cc - r2) - T(16) * Eps<T>::v * (cc + r2);
       }
-      const GEAR_CAS T* rec = V.ocull8 + (size_t)8 * o0;
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        T t = a0 + rec[8 * k + 4];
-        t = t_fma(rec[8 * k + 0], c.x, t);
-        t = t_fma(rec[8 * k + 1], c.y, t);
-        t = t_fma(rec[8 * k + 2], c.z, t);
-        t = t_fma(rec[8 * k + 3], rho, t);
-        m = __builtin_amdgcn_alignbit(m, sign_bits(t), 31);  // m = (m << 1) | (t < 0)
-      }
+      // four blocks of 8 obstacles; the next block's scalar loads are issued before the current
+      // block's arithmetic so that their latency hides behind 48 VALU ops
+      const GEAR_CAS T* rec = V.ocull8 + (size_t)5 * o0;
+      CullBlock<T> b0, b1;
+      b0.load(rec);
+      b1.load(rec + 40);
+      m = b0.sweep(m, c, rho, a0);
+      b0.load(rec + 80);
+      m = b1.sweep(m, c, rho, a0);
+      b1.load(rec + 120);
+      m = b0.sweep(m, c, rho, a0);
+      m = b1.sweep(m, c, rho, a0);
       if (COUNT) npairs += (unsigned)min(32, S.n_obs - o0 > 0 ? S.n_obs - o0 : 0);
       item_base = ((unsigned)o0 << 16) | ((unsigned)s << 6) | (unsigned)lane;
       if (env_done) m = 0;
@@ -316,6 +340,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
           const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
           valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
         }
+        if (dbg_no_drain) valid = false;
         if (valid) {
           const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa);
           const Pose<T> wa = st.get(S.n_slots + sa, ln);
@@ -346,6 +371,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
             const unsigned hw = hits[(sf2 ? 2 : 0) + (ln2 >> 5)];
             v2 = ((hw >> (ln2 & 31)) & 1u) == 0;
           }
+          if (dbg_no_exact) v2 = false;
           if (v2) {
             const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa2);
             const Pose<T> wa = st.get(S.n_slots + sa2, ln2);

@@ -9,6 +9,7 @@
 //   Compound<f64>::from_urdf_robot                   src/collision/collision_checker.rs:349-369
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <map>
 #include <string>
@@ -189,6 +190,8 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
         for (int k = 0; k < 3; k++) s.lt[k] = T(d.t[k] + rc[k]);
       }
       for (int k = 0; k < 3; k++) s.bc[k] = T(0);
+      // local bounding box (centred after the shift), padded a little: stage 1 uses it as a prefilter
+      for (int k = 0; k < 3; k++) s.half[k] = T((hi[k] - lo[k]) * 0.5 * (1.0 + 1e-6) + 1e-9);
       s.br = T(std::sqrt(r2) * (1.0 + 1e-6));
       for (size_t i = 0; i < v.size(); i++) H.verts.push_back(T(v[i] - c[i % 3]));
       for (size_t pl = 0; pl < planes.size() / 4; pl++) {
@@ -295,6 +298,7 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
     }
     H.nodes[k].shape_end = (int)H.rshapes.size();
   }
+  std::vector<std::array<double, 5>> cull_rec;
   // obstacles: world poses; cull record = world bounding sphere, radius pre-inflated by the margin
   for (int s = 0; s < o.n_shapes; s++) {
     ShapeDev<T> sd;
@@ -317,14 +321,14 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
     const double eps = sizeof(T) == 4 ? 1.2e-7 : 2.3e-16;
     double ox = (double)sd.lt[0] + cx, oy = (double)sd.lt[1] + cy, oz = (double)sd.lt[2] + cz;
     double R = rr * (1.0 + 1e-5) + 1e-9, c2 = ox * ox + oy * oy + oz * oz;
-    double rec[8] = {-2 * ox, -2 * oy, -2 * oz, -2 * R, c2 - R * R - 16 * eps * (c2 + R * R), 0, 0, 0};
-    for (double x : rec) H.ocull8.push_back(T(x));
+    cull_rec.push_back({-2 * ox, -2 * oy, -2 * oz, -2 * R, c2 - R * R - 16 * eps * (c2 + R * R)});
   }
-  while ((H.ocull8.size() / 8) % 32 != 0) {
-    // far dummy: k is huge and positive, the test value can never go negative
-    const double rec[8] = {0, 0, 0, 0, 1e30, 0, 0, 0};
-    for (double x : rec) H.ocull8.push_back(T(x));
-  }
+  // far dummies pad the sweep to whole groups of 32: k is huge and positive, the test value never goes negative
+  while (cull_rec.size() % 32 != 0) cull_rec.push_back({0, 0, 0, 0, 1e30});
+  // blocks of 8 obstacles, component-major inside a block: [block][5][8]
+  H.ocull8.assign(cull_rec.size() * 5, T(0));
+  for (size_t i = 0; i < cull_rec.size(); i++)
+    for (int comp = 0; comp < 5; comp++) H.ocull8[(i / 8) * 40 + comp * 8 + (i % 8)] = T(cull_rec[i][comp]);
   // self pairs -> shape ranges; a pair whose joint has no model never yields
   // (collision_checker.rs:150-159)
   for (int p = 0; p < r.n_pairs; p++) {

@@ -76,9 +76,11 @@ struct SceneDev {
   const ShapeDev<T>* rshapes;
   const ShapeDev<T>* oshapes;
   const T* ocull;  // [n_obs][4]: world bounding sphere cx,cy,cz and radius + margin (pre-inflated)
-  // [n_obs_pad][8] cull records for the batched kernel, n_obs_pad a multiple of 32 (tail = far dummies):
-  //   -2cx, -2cy, -2cz, -2R, |c|^2 - R^2 - tau, 0, 0, 0     with R = obstacle radius + margin (inflated)
-  // so that  d^2 - (rho + R)^2 = (|p|^2 - rho^2) + k + p . (-2c) + rho * (-2R)  costs five VALU ops per pair.
+  // cull records for the batched kernel in blocks of 8 obstacles, component-major inside a block:
+  // [n_obs_pad / 8][5][8] = -2cx, -2cy, -2cz, -2R, k  with R = obstacle radius + margin (inflated) and
+  // k = |c|^2 - R^2 - tau; n_obs_pad is a multiple of 32 (tail = far dummies).  Then
+  //   d^2 - (rho + R)^2 = (|p|^2 - rho^2) + k + p . (-2c) + rho * (-2R)      (five VALU ops per pair)
+  // and a block is 40 consecutive dwords: wide scalar loads, one block ahead of the arithmetic.
   const T* ocull8;
   int32_t n_obs_pad, pad2;
   const PairDev* pairs;
