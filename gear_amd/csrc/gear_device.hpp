@@ -50,6 +50,10 @@ GD void t_sincos(float x, float* s, float* c) {
   *c = (float)cd;
 }
 GD void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+GD float t_atan2(float y, float x) { return atan2f(y, x); }
+GD double t_atan2(double y, double x) { return atan2(y, x); }
+GD float t_rint(float x) { return rintf(x); }
+GD double t_rint(double x) { return rint(x); }
 template <class T> GD T t_max(T a, T b) { return a > b ? a : b; }
 template <class T> GD T t_min(T a, T b) { return a < b ? a : b; }
 
@@ -122,12 +126,32 @@ template <class T> struct ShapeRef {
   T br;        // bounding radius
   int vb, vc;  // mesh vertex range
   int fb, fc;  // mesh plane range
+  int pn;      // > 0: regular pn-gon prism along z (vertices vb..vb+pn-1 bottom ring, vb+pn.. top ring)
 };
+
+template <class T> GD V3<T> sel(bool k, V3<T> x, V3<T> y) { return {k ? x.x : y.x, k ? x.y : y.y, k ? x.z : y.z}; }
 
 // support point of the CORE shape (ball -> its centre) in shape-local direction d
 template <class T, class VP> GD V3<T> support_core(const ShapeRef<T>& s, VP verts, V3<T> d) {
   if (s.kind == SK_BOX) return {t_copysign(s.half.x, d.x), t_copysign(s.half.y, d.y), t_copysign(s.half.z, d.z)};
   if (s.kind == SK_BALL) return {T(0), T(0), T(0)};
+  if (s.pn > 0) {
+    // regular prism: the ring vertex nearest the direction's azimuth (its two neighbours are
+    // compared too, which covers the rounding of the angle and of the table's accumulated angles);
+    // the ring is chosen by the sign of d.z
+    const int n = s.pn;
+    int k = (int)t_rint(t_atan2(d.y, d.x) * (T(n) * T(0.15915494309189533577)));
+    k = k < 0 ? k + n : k;
+    k = k >= n ? k - n : k;
+    const int km = k == 0 ? n - 1 : k - 1, kp = k == n - 1 ? 0 : k + 1;
+    const int ring = s.vb + (d.z < T(0) ? 0 : n);
+    V3<T> p0{verts[3 * (ring + km)], verts[3 * (ring + km) + 1], verts[3 * (ring + km) + 2]};
+    V3<T> p1{verts[3 * (ring + k)], verts[3 * (ring + k) + 1], verts[3 * (ring + k) + 2]};
+    V3<T> p2{verts[3 * (ring + kp)], verts[3 * (ring + kp) + 1], verts[3 * (ring + kp) + 2]};
+    const T d0 = dot(p0, d), d1 = dot(p1, d), d2 = dot(p2, d);
+    V3<T> best = sel(d0 > d1, p0, p1);
+    return sel(d2 > t_max(d0, d1), p2, best);
+  }
   V3<T> best{verts[3 * s.vb], verts[3 * s.vb + 1], verts[3 * s.vb + 2]};
   T bd = dot(best, d);
   for (int j = 1; j < s.vc; j++) {
@@ -144,8 +168,6 @@ template <class T, class VP> GD V3<T> support_core(const ShapeRef<T>& s, VP vert
 // The four points live in named registers (runtime-indexed arrays would be
 // demoted to scratch memory); p0..p(n-1) are valid.
 template <class T> struct Simplex { V3<T> a, b, c, d; int n; };
-
-template <class T> GD V3<T> sel(bool k, V3<T> x, V3<T> y) { return {k ? x.x : y.x, k ? x.y : y.y, k ? x.z : y.z}; }
 
 template <class T> GD void simplex_push(Simplex<T>& s, V3<T> w) {
   if (s.n == 1) s.b = w;

@@ -13,6 +13,7 @@
 
 #include "../../include/gear_hip.h"
 #include "gear_kernels.hpp"
+#include "gear_pipeline.hpp"
 #include "gear_scene.hpp"
 
 using namespace gear_hip;
@@ -70,6 +71,8 @@ struct gh_scene {
   hipStream_t stream = nullptr;
   std::mutex mu;
   DevBuf q, flags, out, edges, store, first;
+  DevBuf p_hdr, p_codes, p_qpose, p_hit, p_exact, p_pc, p_pstore;  // pipeline workspace (gear_pipeline.hpp)
+  unsigned item_cap = 1024;  // survivor items per sweep wave before the fused path takes the wave over
   CountersDev* counters = nullptr;
   size_t elem() const { return precision == 32 ? 4 : 8; }
 };
@@ -158,22 +161,117 @@ int for_chunks(gh_scene* sc, size_t n, const StorePlan& plan, F&& launch) {
 
 unsigned grid_for(size_t n) { return (unsigned)((n + kWave - 1) / kWave); }
 
-template <class T>
-void launch_check(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, uint8_t* flags,
-                  hipStream_t st, bool counted, const StorePlan& plan, void* gs, size_t gstride) {
-  const size_t lds = plan.lds_bytes + kQueueBytes;
+// shapes per sweep unit: the instantiation that wastes the fewest shape slots (ties: the larger K)
+int pick_chunk(int n_shapes) {
+  const int ks[3] = {9, 7, 5};
+  int best = 9, waste = 1 << 30;
+  for (int k : ks) {
+    int w = (n_shapes + k - 1) / k * k - n_shapes;
+    if (w < waste) { waste = w; best = k; }
+  }
+  return best;
+}
+
+template <class T, int K>
+void launch_check_k(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, uint8_t* flags,
+                    hipStream_t st, bool counted, const StorePlan& plan, void* gs, size_t gstride, const unsigned* hit) {
+  const size_t lds = plan.lds_bytes + queue_bytes(K);
   const dim3 grid(grid_for(cnt)), block(kWave);
   if (plan.global) {
-    if (counted) hipLaunchKernelGGL((k_check<T, true, true>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
-    else hipLaunchKernelGGL((k_check<T, false, true>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
+    if (counted) hipLaunchKernelGGL((k_check<T, true, true, K>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride, hit);
+    else hipLaunchKernelGGL((k_check<T, false, true, K>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride, hit);
   } else {
-    if (counted) hipLaunchKernelGGL((k_check<T, true, false>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
-    else hipLaunchKernelGGL((k_check<T, false, false>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride);
+    if (counted) hipLaunchKernelGGL((k_check<T, true, false, K>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride, hit);
+    else hipLaunchKernelGGL((k_check<T, false, false, K>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride, hit);
   }
 }
 
+template <class T>
+void launch_check(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, uint8_t* flags,
+                  hipStream_t st, bool counted, const StorePlan& plan, void* gs, size_t gstride,
+                  const unsigned* hit = nullptr) {
+  switch (pick_chunk(sc->L)) {
+    case 5: launch_check_k<T, 5>(sc, S, q, cnt, what, flags, st, counted, plan, gs, gstride, hit); break;
+    case 7: launch_check_k<T, 7>(sc, S, q, cnt, what, flags, st, counted, plan, gs, gstride, hit); break;
+    default: launch_check_k<T, 9>(sc, S, q, cnt, what, flags, st, counted, plan, gs, gstride, hit); break;
+  }
+}
+
+// ---- the pipeline (gear_pipeline.hpp) ------------------------------------------------------------
+constexpr size_t kPipeChunk = size_t(1) << 19;  // configurations per pipeline pass
+constexpr size_t kPipeMin = size_t(1) << 14;    // smaller batches take the fused kernel alone
+constexpr uint32_t kForceFused = 0x1000u, kForcePipe = 0x2000u;  // `what` bits for tests and profiling
+
+template <class T, int K>
+void launch_sweep_k(const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, const PipeWs<T>& W, int lds_centres,
+                    size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_sweep<T, K>), dim3(grid_for(cnt)), dim3(kWave), lds, st, S, q, cnt, what, W, lds_centres);
+}
+
+template <class T>
+int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags,
+                 hipStream_t st) {
+  const size_t chunk = std::min((n + kWave - 1) / kWave * kWave, kPipeChunk);
+  const size_t waves = chunk / kWave;
+  const bool do_self = (what & 2u) && S.n_spairs > 0;
+  PipeWs<T> W{};
+  W.cap = sc->item_cap;
+  W.cap2 = (unsigned)std::min<size_t>(chunk * 2, 0x7fffffffu);
+  W.stride = chunk;
+  int rc;
+  if ((rc = sc->p_hdr.ensure(waves * sizeof(WaveHdr))) || (rc = sc->p_codes.ensure(waves * W.cap * 4)) ||
+      (rc = sc->p_qpose.ensure(waves * W.cap * 7 * sizeof(T))) || (rc = sc->p_hit.ensure(chunk * 4)) ||
+      (rc = sc->p_exact.ensure((size_t)W.cap2 * 4)) || (rc = sc->p_pc.ensure(sizeof(PipeCounters))) ||
+      (do_self && (rc = sc->p_pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
+    return rc;
+  W.hdr = (WaveHdr*)sc->p_hdr.p;
+  W.codes = (unsigned*)sc->p_codes.p;
+  W.qpose = (T*)sc->p_qpose.p;
+  W.hit = (unsigned*)sc->p_hit.p;
+  W.exact = (unsigned*)sc->p_exact.p;
+  W.pc = (PipeCounters*)sc->p_pc.p;
+  W.pstore = (T*)sc->p_pstore.p;
+  // the fused kernel is the last stage (flag conversion + re-checks): it needs its own pose columns
+  StorePlan plan = plan_store(sc, true);
+  void* gs = nullptr;
+  size_t gstride = 0;
+  if (plan.global) {
+    if ((rc = sc->store.ensure(plan.slots * 7 * chunk * sizeof(T)))) return rc;
+    gs = sc->store.p;
+    gstride = chunk;
+  }
+  const size_t slot_bytes = (size_t)S.n_slots * 7 * kWave * sizeof(T);
+  const size_t cen_bytes = (size_t)S.n_shapes * 3 * kWave * sizeof(T);
+  const int lds_centres = do_self && cen_bytes <= 24 * 1024;
+  const size_t lds = slot_bytes + (lds_centres ? cen_bytes : 0);
+  const int K = pick_chunk(sc->L);
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t cnt = std::min(chunk, n - off);
+    const T* qc = q + off * sc->D;
+    GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), st));
+    switch (K) {
+      case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, lds, st); break;
+      case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, lds, st); break;
+      default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, lds, st); break;
+    }
+    hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kWave), 0, st, S, cnt, what, W);
+    const unsigned g2 = (unsigned)std::min<size_t>(2048, (cnt + 255) / 256);
+    hipLaunchKernelGGL((k_narrow2<T>), dim3(g2), dim3(256), 0, st, S, what, W);
+    launch_check<T>(sc, S, qc, cnt, what, flags + off, st, false, plan, gs, gstride, W.hit);
+    GH_HIP(hipGetLastError());
+  }
+  return GH_OK;
+}
+
 int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted) {
-  if (!(sc->margin > 0)) what = 0;  // distance >= 0 is never < a non-positive margin: only limits can fail
+  if (!(sc->margin > 0)) what &= ~3u;  // distance >= 0 is never < a non-positive margin: only limits can fail
+  const size_t slot_bytes = (size_t)sc->n_slots * 7 * kWave * sc->elem();
+  const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 && slot_bytes <= 32 * 1024;
+  if (pipe_ok && !(what & kForceFused) && (n >= kPipeMin || (what & kForcePipe))) {
+    if (n == 0) return GH_OK;
+    return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st)
+                               : pipeline_dev<double>(sc, sc->s64, (const double*)q, n, what, flags, st);
+  }
   StorePlan plan = plan_store(sc, true);  // the batched kernel keeps every shape pose in the lane's column
   return for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
     if (sc->precision == 32)
@@ -265,6 +363,8 @@ void gh_scene_destroy(gh_scene* sc) {
     for (void* p : sc->tables) (void)hipFree(p);
     if (sc->counters) (void)hipFree(sc->counters);
     sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
+    sc->p_hdr.release(); sc->p_codes.release(); sc->p_qpose.release(); sc->p_hit.release(); sc->p_exact.release();
+    sc->p_pc.release(); sc->p_pstore.release();
   }
   delete sc;
 }

@@ -28,6 +28,7 @@ template <class U> GD const GEAR_CAS U* to_cas(const U* p) {
 }
 
 constexpr int kWave = 64;
+constexpr unsigned kHitRedo = 0x80u;  // pipeline hit word, bit 7: re-check this configuration with the fused kernel
 
 template <class T> struct Views {
   const GEAR_CAS NodeDev<T>* nodes;
@@ -54,6 +55,7 @@ template <class T, class SP> GD ShapeRef<T> shape_ref(SP sh) {
   r.br = sh->br;
   r.vb = sh->v_begin; r.vc = sh->v_count;
   r.fb = sh->f_begin; r.fc = sh->f_count;
+  r.pn = sh->prism_n;
   return r;
 }
 template <class T, class SP> GD Pose<T> shape_pose(SP sh) {
@@ -142,7 +144,6 @@ template <class T> __device__ PoseStore<T> make_store(T* gstore, size_t gstride,
 // ---------------------------------------------------------------------------
 constexpr int kQCap = 448;  // stage-1 queue entries per wave
 constexpr int kGCap = 192;  // stage-2 (exact) queue entries per wave
-constexpr size_t kQueueBytes = (kQCap + kGCap + 4) * 4;
 
 GD float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 GD double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -199,15 +200,85 @@ template <bool GSTORE> __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <class T, bool COUNT, bool GSTORE>
+// Sweep of K robot shapes against 32 obstacles (4 blocks of 8).  Obstacle blocks are the outer loop and
+// the K shapes the inner one: a block's 40 scalars feed 48*K VALU ops, and exactly ONE block load is
+// in flight while the previous block is being used.  (Scalar loads return out of order, so the only
+// wait there is is "all outstanding loads": a second load in flight would be waited for as soon as
+// the first one's data is needed.)
+// One obstacle block against K shapes.  For a fixed obstacle the K shapes are K independent chains
+// (add, 4 fma, alignbit), issued stage by stage so that dependent instructions sit K slots apart.
+template <class T, int K>
+__device__ __forceinline__ void sweep_block(const CullBlock<T>& b, const V3<T> (&c)[K], const T (&rho)[K],
+                                            const T (&a0)[K], unsigned (&m)[K]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    T t[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = a0[j] + b.v[32 + k];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[k], c[j].x, t[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[8 + k], c[j].y, t[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[16 + k], c[j].z, t[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[24 + k], rho[j], t[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < K; j++) m[j] = __builtin_amdgcn_alignbit(m[j], sign_bits(t[j]), 31);  // m = (m << 1) | (t < 0)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Sweep of K robot shapes against 32 obstacles (4 blocks of 8).  Obstacle blocks are the outer loop and
+// the K shapes the inner one: a block's 40 scalars feed 48*K VALU ops, and exactly ONE block load is
+// in flight while the previous block is being used.  (Scalar loads return out of order, so the only
+// wait there is is "all outstanding loads": a second load in flight would be waited for as soon as
+// the first one's data is needed.)
+template <class T, int K>
+__device__ __forceinline__ void sweep_unit(const GEAR_CAS T* rec, const V3<T> (&c)[K], const T (&rho)[K],
+                                           const T (&a0)[K], unsigned (&m)[K]) {
+  CullBlock<T> A, B;
+#pragma unroll
+  for (int j = 0; j < K; j++) m[j] = 0u;
+  A.load(rec);
+  __builtin_amdgcn_sched_barrier(0);
+  B.load(rec + 40);
+  sweep_block<T, K>(A, c, rho, a0, m);
+  A.load(rec + 80);
+  sweep_block<T, K>(B, c, rho, a0, m);
+  B.load(rec + 120);
+  sweep_block<T, K>(A, c, rho, a0, m);
+  sweep_block<T, K>(B, c, rho, a0, m);
+}
+
+constexpr size_t queue_bytes(int K) { return (size_t)(kQCap + kGCap + 4 + K * kWave) * 4; }
+
+template <class T, bool COUNT, bool GSTORE, int K>
 __global__ void __launch_bounds__(kWave)
 k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t* __restrict__ flags,
-        CountersDev* __restrict__ ctr, T* gstore, size_t gstride) {
+        CountersDev* __restrict__ ctr, T* gstore, size_t gstride, const unsigned* __restrict__ hit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
   const int lane = threadIdx.x;
   size_t i = (size_t)blockIdx.x * kWave + lane;
   const bool live = i < n;
+  // hit != nullptr: last stage of the pipeline (gear_pipeline.hpp).  hit[i] already holds the flags
+  // of configuration i unless bit 7 asks for a re-check; a wave without such a lane only converts.
+  unsigned prior = 0;
+  bool need = true;
+  if (hit) {
+    prior = live ? hit[i] : 0u;
+    need = (prior & kHitRedo) != 0;
+    if (__ballot(need) == 0) {
+      if (live) flags[i] = (prior & 4u) ? (uint8_t)4 : (uint8_t)(prior & 3u);
+      return;
+    }
+  }
   if (!live) i = n - 1;  // keep the lane on valid data; it pushes and stores nothing
   const T* qrow = q + i * (size_t)S.n_cols;
   const int pose_slots = S.n_slots + S.n_shapes;
@@ -222,6 +293,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
   }
   unsigned* q2 = q1 + kQCap;
   unsigned* hits = q2 + kGCap;  // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
+  unsigned* mst = hits + 4;     // [K][64]: survivor masks of the current sweep unit (each lane reads its own)
   if (lane < 4) hits[lane] = 0;
 
   const bool do_env = (what & 1u) && S.n_obs > 0;
@@ -246,48 +318,55 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
   wave_sync<GSTORE>();
 
   // ---- 2 + 3. cull sweep feeding the survivor queues -----------------------
-  const int env_groups = do_env ? S.n_shapes * (S.n_obs_pad / 32) : 0;
+  // A unit is K shapes x 32 obstacles (env) or 32 self shape pairs.
+  const int n_og = S.n_obs_pad / 32;
+  const int env_units = do_env ? (S.n_shapes + K - 1) / K * n_og : 0;
   const int self_groups = do_self ? (S.n_spairs + 31) / 32 : 0;
-  const int groups = env_groups + self_groups;
-  const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
+  const int units = env_units + self_groups;
+  const bool push_ok = live && ok && need;  // the reference evaluates no collision after a limit error
   bool env_done = false, self_done = false;
   int qn = 0, gn = 0;  // wave-uniform queue fills
-  int s = 0, o0 = 0;
-  V3<T> c{T(0), T(0), T(0)};
-  T a0 = T(0), rho = T(0);
+  int s0 = 0, o0 = 0;
+  V3<T> c[K];
+  T a0[K], rho[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) { c[j] = {T(0), T(0), T(0)}; a0[j] = T(0); rho[j] = T(0); }
 
-  for (int g = 0; g < groups; g++) {
-    unsigned m = 0;
-    unsigned item_base;
-    const bool is_env = g < env_groups;
+  for (int u = 0; u < units; u++) {
+    const bool is_env = u < env_units;
+    int nsub = 1;
+    unsigned unit_base;
     if (is_env) {
       if (o0 == 0) {
-        c = st.centre(S.n_slots + s, lane);
-        rho = V.rshapes[s].br;
-        asm volatile("" : "+v"(rho));  // keep the radius in a VGPR: the obstacle record supplies the SGPR operand
-        T cc = dot(c, c), r2 = rho * rho;
-        a0 = (cc - r2) - T(16) * Eps<T>::v * (cc + r2);
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          const int s = min(s0 + j, S.n_shapes - 1);  // a chunk's tail repeats the last shape; its masks are not read
+          c[j] = st.centre(S.n_slots + s, lane);
+          T r = V.rshapes[s].br;
+          asm volatile("" : "+v"(r));  // keep the radius in a VGPR: the obstacle record supplies the SGPR operand
+          rho[j] = r;
+          const T cc = dot(c[j], c[j]), r2 = r * r;
+          a0[j] = (cc - r2) - T(16) * Eps<T>::v * (cc + r2);
+        }
       }
-      // four blocks of 8 obstacles; the next block's scalar loads are issued before the current
-      // block's arithmetic so that their latency hides behind 48 VALU ops
-      const GEAR_CAS T* rec = V.ocull8 + (size_t)5 * o0;
-      CullBlock<T> b0, b1;
-      b0.load(rec);
-      b1.load(rec + 40);
-      m = b0.sweep(m, c, rho, a0);
-      b0.load(rec + 80);
-      m = b1.sweep(m, c, rho, a0);
-      b1.load(rec + 120);
-      m = b0.sweep(m, c, rho, a0);
-      m = b1.sweep(m, c, rho, a0);
-      if (COUNT) npairs += (unsigned)min(32, S.n_obs - o0 > 0 ? S.n_obs - o0 : 0);
-      item_base = ((unsigned)o0 << 16) | ((unsigned)s << 6) | (unsigned)lane;
-      if (env_done) m = 0;
+      unsigned m[K];
+      if (what & 0x800u) {  // profiling ablation: no sweep
+#pragma unroll
+        for (int j = 0; j < K; j++) m[j] = 0u;
+      } else {
+        sweep_unit<T, K>(V.ocull8 + (size_t)5 * o0, c, rho, a0, m);
+      }
+#pragma unroll
+      for (int j = 0; j < K; j++) mst[j * kWave + lane] = m[j];
+      nsub = min(K, S.n_shapes - s0);
+      if (COUNT) npairs += (unsigned)(nsub * min(32, S.n_obs - o0 > 0 ? S.n_obs - o0 : 0));
+      unit_base = ((unsigned)o0 << 16) | ((unsigned)s0 << 6) | (unsigned)lane;
       o0 += 32;
-      if (o0 >= S.n_obs_pad) { o0 = 0; s++; }
+      if (o0 >= S.n_obs_pad) { o0 = 0; s0 += K; }
     } else {
-      const int p0 = (g - env_groups) * 32;
+      const int p0 = (u - env_units) * 32;
       const int cnt = min(32, S.n_spairs - p0);
+      unsigned m = 0;
       for (int k = 0; k < 32; k++) {
         unsigned bit = 0;
         if (k < cnt) {
@@ -298,107 +377,116 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
         }
         m = (m << 1) | bit;
       }
+      mst[lane] = m;
       if (COUNT) npairs += (unsigned)cnt;
-      item_base = 0x80000000u | ((unsigned)p0 << 6) | (unsigned)lane;
-      if (self_done) m = 0;
+      unit_base = 0x80000000u | ((unsigned)p0 << 6) | (unsigned)lane;
     }
-    if (!push_ok) m = 0;
-    if (COUNT) lc.cull_pass += __popc(m);
 
-    const bool last_group = g == groups - 1;
-    for (;;) {
-      // push one survivor per lane per round while the queue has room for a full round
-      while (qn + kWave <= kQCap) {
-        const bool has = m != 0;
-        const unsigned long long b = __ballot(has);
-        if (b == 0) break;
-        if (has) {
-          const int z = __clz(m);  // bit 31 - z  <->  k = z within the group
-          m &= ~(0x80000000u >> z);
-          const unsigned it = is_env ? item_base + ((unsigned)z << 16) : item_base + ((unsigned)z << 6);
-          q1[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = it;
-        }
-        qn += __popcll(b);
-      }
-      const bool more = __ballot(m != 0) != 0;
-      if (!more && !(last_group && (qn > 0 || gn > 0))) break;
-      const bool final = last_group && !more;  // last drain of the wave: empty both queues
+    for (int j = 0; j < nsub; j++) {
+      unsigned m = mst[j * kWave + lane];
+      const unsigned item_base = unit_base + ((unsigned)j << 6);
+      if (is_env ? env_done : self_done) m = 0;
+      if (!push_ok || (what & 0x400u)) m = 0;  // 0x400: profiling ablation, no push
+      if (COUNT) lc.cull_pass += __popc(m);
 
-      // ---- drain: the single narrow-phase site -----------------------------
-      wave_sync<GSTORE>();
-      for (int base = 0; base < qn || (final && base == 0); base += kWave) {
-        const int j = base + lane;
-        bool valid = j < qn;
-        const unsigned it = valid ? q1[j] : 0u;
-        const int ln = it & 63;
-        const bool sf = (it >> 31) != 0;
-        int sa, sbx;
-        if (sf) { const int pi = (it >> 6) & 0x1ffffff; sa = V.spairs[4 * pi]; sbx = V.spairs[4 * pi + 1]; }
-        else { sa = (it >> 6) & 1023; sbx = (it >> 16) & 32767; }
-        int r = PR_FREE;
-        if (valid) {
-          const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
-          valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
-        }
-        if (dbg_no_drain) valid = false;
-        if (valid) {
-          const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa);
-          const Pose<T> wa = st.get(S.n_slots + sa, ln);
-          ShapeRef<T> B;
-          Pose<T> wb;
-          if (sf) { B = shape_ref<T>(V.rshapes + sbx); wb = st.get(S.n_slots + sbx, ln); }
-          else { B = shape_ref<T>(V.oshapes + sbx); wb = shape_pose<T>(V.oshapes + sbx); }
-          r = pair_stage1<T, COUNT>(A, wa, B, wb, margin, lc);
-          if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
-        }
-        const bool ex = r == PR_EXACT;
-        const unsigned long long eb = __ballot(ex);
-        if (ex) q2[gn + __builtin_amdgcn_mbcnt_hi((unsigned)(eb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eb, 0u))] = it;
-        gn += __popcll(eb);
-        const bool final_drain = final && base + kWave >= qn;
-        while (gn >= kWave || (final_drain && gn > 0)) {
-          wave_sync<GSTORE>();
-          const int take = gn >= kWave ? kWave : gn;
-          const int g0 = gn - take;
-          bool v2 = lane < take;
-          const unsigned it2 = v2 ? q2[g0 + lane] : 0u;
-          const int ln2 = it2 & 63;
-          const bool sf2 = (it2 >> 31) != 0;
-          int sa2, sb2;
-          if (sf2) { const int pi = (it2 >> 6) & 0x1ffffff; sa2 = V.spairs[4 * pi]; sb2 = V.spairs[4 * pi + 1]; }
-          else { sa2 = (it2 >> 6) & 1023; sb2 = (it2 >> 16) & 32767; }
-          if (v2) {
-            const unsigned hw = hits[(sf2 ? 2 : 0) + (ln2 >> 5)];
-            v2 = ((hw >> (ln2 & 31)) & 1u) == 0;
+      const bool last_group = u == units - 1 && j == nsub - 1;
+      for (;;) {
+        // push one survivor per lane per round while the queue has room for a full round
+        while (qn + kWave <= kQCap) {
+          const bool has = m != 0;
+          const unsigned long long b = __ballot(has);
+          if (b == 0) break;
+          if (has) {
+            const int z = __clz(m);  // bit 31 - z  <->  k = z within the group
+            m &= ~(0x80000000u >> z);
+            const unsigned it = is_env ? item_base + ((unsigned)z << 16) : item_base + ((unsigned)z << 6);
+            q1[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = it;
           }
-          if (dbg_no_exact) v2 = false;
-          if (v2) {
-            const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa2);
-            const Pose<T> wa = st.get(S.n_slots + sa2, ln2);
+          qn += __popcll(b);
+        }
+        const bool more = __ballot(m != 0) != 0;
+        if (!more && !(last_group && (qn > 0 || gn > 0))) break;
+        const bool final = last_group && !more;  // last drain of the wave: empty both queues
+
+        // ---- drain: the single narrow-phase site -----------------------------
+        wave_sync<GSTORE>();
+        for (int base = 0; base < qn || (final && base == 0); base += kWave) {
+          const int jq = base + lane;
+          bool valid = jq < qn;
+          const unsigned it = valid ? q1[jq] : 0u;
+          const int ln = it & 63;
+          const bool sf = (it >> 31) != 0;
+          int sa, sbx;
+          if (sf) { const int pi = (it >> 6) & 0x1ffffff; sa = V.spairs[4 * pi]; sbx = V.spairs[4 * pi + 1]; }
+          else { sa = (it >> 6) & 1023; sbx = (it >> 16) & 32767; }
+          int r = PR_FREE;
+          if (valid) {
+            const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
+            valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
+          }
+          if (dbg_no_drain) valid = false;
+          if (valid) {
+            const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa);
+            const Pose<T> wa = st.get(S.n_slots + sa, ln);
             ShapeRef<T> B;
             Pose<T> wb;
-            if (sf2) { B = shape_ref<T>(V.rshapes + sb2); wb = st.get(S.n_slots + sb2, ln2); }
-            else { B = shape_ref<T>(V.oshapes + sb2); wb = shape_pose<T>(V.oshapes + sb2); }
-            if (pair_stage2<T, COUNT>(A, wa, B, wb, V.verts, V.planes, margin, lc))
-              atomicOr(&hits[(sf2 ? 2 : 0) + (ln2 >> 5)], 1u << (ln2 & 31));
+            if (sf) { B = shape_ref<T>(V.rshapes + sbx); wb = st.get(S.n_slots + sbx, ln); }
+            else { B = shape_ref<T>(V.oshapes + sbx); wb = shape_pose<T>(V.oshapes + sbx); }
+            r = pair_stage1<T, COUNT>(A, wa, B, wb, margin, lc);
+            if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
           }
-          gn = g0;
-          wave_sync<GSTORE>();
+          const bool ex = r == PR_EXACT;
+          const unsigned long long eb = __ballot(ex);
+          if (ex) q2[gn + __builtin_amdgcn_mbcnt_hi((unsigned)(eb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eb, 0u))] = it;
+          gn += __popcll(eb);
+          const bool final_drain = final && base + kWave >= qn;
+          while (gn >= kWave || (final_drain && gn > 0)) {
+            wave_sync<GSTORE>();
+            const int take = gn >= kWave ? kWave : gn;
+            const int g0 = gn - take;
+            bool v2 = lane < take;
+            const unsigned it2 = v2 ? q2[g0 + lane] : 0u;
+            const int ln2 = it2 & 63;
+            const bool sf2 = (it2 >> 31) != 0;
+            int sa2, sb2;
+            if (sf2) { const int pi = (it2 >> 6) & 0x1ffffff; sa2 = V.spairs[4 * pi]; sb2 = V.spairs[4 * pi + 1]; }
+            else { sa2 = (it2 >> 6) & 1023; sb2 = (it2 >> 16) & 32767; }
+            if (v2) {
+              const unsigned hw = hits[(sf2 ? 2 : 0) + (ln2 >> 5)];
+              v2 = ((hw >> (ln2 & 31)) & 1u) == 0;
+            }
+            if (dbg_no_exact) v2 = false;
+            if (v2) {
+              const ShapeRef<T> A = shape_ref<T>(V.rshapes + sa2);
+              const Pose<T> wa = st.get(S.n_slots + sa2, ln2);
+              ShapeRef<T> B;
+              Pose<T> wb;
+              if (sf2) { B = shape_ref<T>(V.rshapes + sb2); wb = st.get(S.n_slots + sb2, ln2); }
+              else { B = shape_ref<T>(V.oshapes + sb2); wb = shape_pose<T>(V.oshapes + sb2); }
+              if (pair_stage2<T, COUNT>(A, wa, B, wb, V.verts, V.planes, margin, lc))
+                atomicOr(&hits[(sf2 ? 2 : 0) + (ln2 >> 5)], 1u << (ln2 & 31));
+            }
+            gn = g0;
+            wave_sync<GSTORE>();
+          }
         }
+        qn = 0;
+        wave_sync<GSTORE>();
+        env_done = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
+        self_done = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
+        if (is_env ? env_done : self_done) m = 0;
+        if (!more) break;
       }
-      qn = 0;
-      wave_sync<GSTORE>();
-      env_done = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
-      self_done = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
-      if (is_env ? env_done : self_done) m = 0;
-      if (!more) break;
     }
   }
 
   wave_sync<GSTORE>();
   const bool env_hit = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
   const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
-  if (live) flags[i] = ok ? (uint8_t)((env_hit ? 1 : 0) | (self_hit ? 2 : 0)) : (uint8_t)4;
+  if (live) {
+    if (need) flags[i] = ok ? (uint8_t)((env_hit ? 1 : 0) | (self_hit ? 2 : 0)) : (uint8_t)4;
+    else flags[i] = (prior & 4u) ? (uint8_t)4 : (uint8_t)(prior & 3u);
+  }
   if (COUNT) {
     // counters live on whichever lane ran the test; only their sums are meaningful
     atomicAdd(&ctr->configs, live ? 1ull : 0ull);

@@ -1,0 +1,383 @@
+// gear_pipeline.hpp — the large-batch form of the check: three lean gfx950 kernels in
+// front of the fused k_check, so that every stage runs at the occupancy and register
+// budget it can use (the fused kernel carries the narrow phase's ~200 VGPRs through
+// its sweep and is limited to two waves per SIMD by its LDS pose columns).
+//
+//   k_sweep    one lane per configuration: limits, FK walk with the world poses of up
+//              to K robot shapes held in REGISTERS; whenever K shapes are ready they
+//              are swept against all obstacle records (obstacle block outer, shapes
+//              inner, records as SGPR operands).  Survivors are appended, pose
+//              included, to the wave's own region of a global queue (no atomics: one
+//              region per wave).  With self pairs: every shape pose also goes to a
+//              global pose store, shape centres to LDS, and the self shape pairs are
+//              swept from there.
+//   k_narrow1  workgroup b = the items of sweep wave b, one item per lane: closed
+//              forms / SAT / box prefilter; hits OR-ed in LDS; undecided items are
+//              appended to one dense exact queue (one atomic per workgroup).
+//   k_narrow2  one lane per exact item: GJK margin query + hollow-mesh rule.
+//   k_check<REDO>  hit word -> flag byte; a wave whose queue region overflowed (or an
+//              exact queue that ran full) is re-checked by the fused path, so the
+//              result never depends on a queue capacity.
+//
+// Reference semantics are unchanged: per configuration this evaluates is_feasible /
+// is_feasible_with_self (src/planner/joint_path_planner.rs:71-84,113-121); only the
+// order in which pairs are looked at differs, and the flags are an OR over pairs.
+#pragma once
+#include "gear_kernels.hpp"
+
+namespace gear_hip {
+
+constexpr int kExLds = 192;           // per-workgroup staging of exact entries in k_narrow1
+constexpr int kMaxItemCap = 1024;     // an exact entry packs the item index into 10 bits
+
+struct WaveHdr {
+  unsigned count;     // items pushed by the wave (may exceed the capacity: then `overflow` is set)
+  unsigned limit_lo;  // lanes whose configuration violates a joint limit
+  unsigned limit_hi;
+  unsigned overflow;
+};
+
+struct PipeCounters {
+  unsigned exact;     // entries in the exact queue
+  unsigned overflow;  // the exact queue ran full
+  unsigned pad[2];
+};
+
+// layout of one launch chunk's workspace
+template <class T> struct PipeWs {
+  WaveHdr* hdr;          // [waves]
+  unsigned* codes;       // [waves][cap]
+  T* qpose;              // [waves][7][cap]  world pose of an env item's robot shape
+  unsigned* hit;         // [configs]
+  unsigned* exact;       // [cap2]  wave << 10 | item
+  PipeCounters* pc;
+  T* pstore;             // [L][7][stride]  every shape pose (self pairs only)
+  size_t stride;
+  unsigned cap, cap2;
+};
+
+__device__ __forceinline__ unsigned lane_rank(unsigned long long b) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+}
+
+// exclusive prefix sum of a small per-lane count over the wave, and the wave total
+__device__ __forceinline__ void wave_offsets(unsigned nl, unsigned& off, unsigned& tot) {
+  const unsigned long long bh = __ballot(nl >= 8u);
+  if (bh == 0) {
+    const unsigned long long b0 = __ballot((nl & 1u) != 0), b1 = __ballot((nl & 2u) != 0), b2 = __ballot((nl & 4u) != 0);
+    off = lane_rank(b0) + 2u * lane_rank(b1) + 4u * lane_rank(b2);
+    tot = (unsigned)__popcll(b0) + 2u * (unsigned)__popcll(b1) + 4u * (unsigned)__popcll(b2);
+  } else {
+    unsigned inc = nl;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    off = inc - nl;
+    tot = __shfl(inc, 63);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_sweep
+// ---------------------------------------------------------------------------
+template <class T, int K>
+__global__ void __launch_bounds__(kWave)
+k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
+  const Views<T> V(S);
+  const int lane = threadIdx.x;
+  const size_t wave = blockIdx.x;
+  const size_t col = wave * kWave + lane;
+  const bool live = col < n;
+  const size_t i = live ? col : n - 1;
+  const T* qrow = q + i * (size_t)S.n_cols;
+  const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)lane};
+  T* cen = reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T));  // [L][3][64] when lds_centres
+
+  const bool ok = limits_ok(S, V, qrow);
+  const bool do_env = (what & 1u) && S.n_obs > 0;
+  const bool do_self = (what & 2u) && S.n_spairs > 0;
+  const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
+  const bool dbg_no_sweep = (what & 0x800u) != 0, dbg_no_push = (what & 0x400u) != 0;  // profiling ablations
+
+  unsigned* codes = W.codes + wave * W.cap;
+  T* qpose = W.qpose + wave * 7 * (size_t)W.cap;
+  unsigned count = 0;  // wave-uniform
+  bool overflow = false;
+
+  const T never = T(1e30);  // a0 of a lane / register slot that must not produce survivors
+  Pose<T> P[K];
+  T a0[K], rho[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    P[j] = {{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
+    a0[j] = never;
+    rho[j] = T(0);
+  }
+  int fill = 0, node = -1;
+  Pose<T> cur{{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
+  const int n_walk = (do_env || do_self) ? S.n_shapes : 0;
+
+  for (int s = 0; s < n_walk; s++) {
+    const GEAR_CAS ShapeDev<T>* sh = V.rshapes + s;
+    const int target = sh->node;
+    while (node < target) {
+      node++;
+      node_world(V, node, qrow, slots, cur);
+    }
+    const Pose<T> ws = pose_mul(cur, shape_pose<T>(sh));
+    if (do_self) {
+      T* b = W.pstore + (size_t)s * 7 * W.stride + col;
+      if (live) {
+        b[0] = ws.t.x; b[W.stride] = ws.t.y; b[2 * W.stride] = ws.t.z;
+        b[3 * W.stride] = ws.r.i; b[4 * W.stride] = ws.r.j; b[5 * W.stride] = ws.r.k; b[6 * W.stride] = ws.r.w;
+      }
+      if (lds_centres) {
+        T* cc = cen + (size_t)s * 3 * kWave + lane;
+        cc[0] = ws.t.x; cc[kWave] = ws.t.y; cc[2 * kWave] = ws.t.z;
+      }
+    }
+    if (!do_env) continue;
+    {
+      T r = sh->br;
+      asm volatile("" : "+v"(r));  // the radius in a VGPR: the obstacle record supplies the SGPR operand
+      const T cc = dot(ws.t, ws.t), r2 = r * r;
+      const T av = push_ok ? (cc - r2) - T(16) * Eps<T>::v * (cc + r2) : never;
+#pragma unroll
+      for (int j = 0; j < K; j++)
+        if (fill == j) { P[j] = ws; a0[j] = av; rho[j] = r; }
+      fill++;
+    }
+    if (fill < K && s != n_walk - 1) continue;
+
+    // ---- sweep the `fill` shapes s0 .. s against every obstacle ----------------
+    const int s0 = s + 1 - fill;
+    V3<T> c[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) c[j] = P[j].t;
+    for (int o0 = 0; o0 < S.n_obs_pad; o0 += 32) {
+      unsigned m[K];
+      if (dbg_no_sweep) {
+#pragma unroll
+        for (int j = 0; j < K; j++) m[j] = 0u;
+      } else {
+        sweep_unit<T, K>(V.ocull8 + (size_t)5 * o0, c, rho, a0, m);
+      }
+      unsigned nl = 0;
+#pragma unroll
+      for (int j = 0; j < K; j++) nl += (unsigned)__popc(m[j]);
+      if (dbg_no_push) nl = 0;
+      if (__ballot(nl != 0) == 0) continue;
+      unsigned off, tot;
+      wave_offsets(nl, off, tot);
+      if (count + tot > W.cap) {
+        overflow = true;
+      } else if (nl != 0) {
+        unsigned pos = count + off;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          unsigned mm = m[j];
+          while (mm != 0) {
+            const int z = __clz(mm);  // bit 31 - z  <->  obstacle o0 + z
+            mm &= ~(0x80000000u >> z);
+            codes[pos] = ((unsigned)(o0 + z) << 16) | ((unsigned)(s0 + j) << 6) | (unsigned)lane;
+            T* b = qpose + pos;
+            b[0] = P[j].t.x; b[W.cap] = P[j].t.y; b[2 * W.cap] = P[j].t.z;
+            b[3 * W.cap] = P[j].r.i; b[4 * W.cap] = P[j].r.j; b[5 * W.cap] = P[j].r.k; b[6 * W.cap] = P[j].r.w;
+            pos++;
+          }
+        }
+      }
+      count += tot;
+    }
+    fill = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) a0[j] = never;
+  }
+
+  // ---- self shape pairs ---------------------------------------------------------
+  if (do_self) {
+    if (!lds_centres) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores -> own loads of the pose store
+    for (int p0 = 0; p0 < S.n_spairs; p0 += 32) {
+      const int cnt = min(32, S.n_spairs - p0);
+      unsigned m = 0;
+      for (int k = 0; k < cnt; k++) {
+        const int s1 = V.spairs[4 * (p0 + k)], s2 = V.spairs[4 * (p0 + k) + 1];
+        V3<T> c1, c2;
+        if (lds_centres) {
+          const T* a = cen + (size_t)s1 * 3 * kWave + lane;
+          const T* b = cen + (size_t)s2 * 3 * kWave + lane;
+          c1 = {a[0], a[kWave], a[2 * kWave]};
+          c2 = {b[0], b[kWave], b[2 * kWave]};
+        } else {
+          const T* a = W.pstore + (size_t)s1 * 7 * W.stride + (live ? col : 0);
+          const T* b = W.pstore + (size_t)s2 * 7 * W.stride + (live ? col : 0);
+          c1 = {a[0], a[W.stride], a[2 * W.stride]};
+          c2 = {b[0], b[W.stride], b[2 * W.stride]};
+        }
+        const V3<T> d = c1 - c2;
+        const T rr = V.spair_r[p0 + k];
+        m |= (push_ok && dot(d, d) < rr * rr) ? (0x80000000u >> k) : 0u;
+      }
+      if (dbg_no_push) m = 0;
+      const unsigned nl = (unsigned)__popc(m);
+      if (__ballot(nl != 0) == 0) continue;
+      unsigned off, tot;
+      wave_offsets(nl, off, tot);
+      if (count + tot > W.cap) {
+        overflow = true;
+      } else {
+        unsigned pos = count + off;
+        while (m != 0) {
+          const int z = __clz(m);
+          m &= ~(0x80000000u >> z);
+          codes[pos++] = 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane;
+        }
+      }
+      count += tot;
+    }
+  }
+
+  const unsigned long long bad = __ballot(live && !ok);
+  if (lane == 0) W.hdr[wave] = {count, (unsigned)bad, (unsigned)(bad >> 32), overflow ? 1u : 0u};
+}
+
+// fetch the two shapes and poses of an item of wave `wave`
+template <class T>
+__device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>& V, const PipeWs<T>& W, size_t wave,
+                                           unsigned j, unsigned code, ShapeRef<T>& A, Pose<T>& wa, ShapeRef<T>& B,
+                                           Pose<T>& wb) {
+  if (code >> 31) {
+    const int pi = (code >> 6) & 0x1ffffff;
+    const int s1 = V.spairs[4 * pi], s2 = V.spairs[4 * pi + 1];
+    const size_t col = wave * kWave + (code & 63u);
+    const T* a = W.pstore + (size_t)s1 * 7 * W.stride + col;
+    const T* b = W.pstore + (size_t)s2 * 7 * W.stride + col;
+    A = shape_ref<T>(V.rshapes + s1);
+    wa = {{a[0], a[W.stride], a[2 * W.stride]}, {a[3 * W.stride], a[4 * W.stride], a[5 * W.stride], a[6 * W.stride]}};
+    B = shape_ref<T>(V.rshapes + s2);
+    wb = {{b[0], b[W.stride], b[2 * W.stride]}, {b[3 * W.stride], b[4 * W.stride], b[5 * W.stride], b[6 * W.stride]}};
+  } else {
+    const int s = (code >> 6) & 1023, o = (code >> 16) & 32767;
+    const T* a = W.qpose + wave * 7 * (size_t)W.cap + j;
+    A = shape_ref<T>(V.rshapes + s);
+    wa = {{a[0], a[W.cap], a[2 * W.cap]}, {a[3 * W.cap], a[4 * W.cap], a[5 * W.cap], a[6 * W.cap]}};
+    B = shape_ref<T>(V.oshapes + o);
+    wb = shape_pose<T>(V.oshapes + o);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_narrow1: workgroup (one wavefront) b handles the items of sweep wave b
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kWave)
+k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
+  __shared__ unsigned hits[4];       // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
+  __shared__ unsigned exq[kExLds];   // staged exact entries
+  const Views<T> V(S);
+  const int lane = threadIdx.x;
+  const size_t wave = blockIdx.x;
+  const WaveHdr h = W.hdr[wave];
+  const size_t cfg = wave * kWave + lane;
+  if (h.overflow) {  // the region ran full: the fused path re-checks these configurations
+    if (cfg < n) W.hit[cfg] = kHitRedo;
+    return;
+  }
+  if (lane < 4) hits[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned* codes = W.codes + wave * W.cap;
+  const T margin = S.margin;
+  LaneCounters lc{0, 0, 0, 0};
+  int en = 0;          // wave-uniform fill of exq
+  bool redo = false;   // the exact queue ran full
+
+  auto flush = [&]() {
+    if (en == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&W.pc->exact, (unsigned)en);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + (unsigned)en > W.cap2) {
+      redo = true;
+    } else {
+      for (int k = lane; k < en; k += kWave) W.exact[base + k] = ((unsigned)wave << 10) | exq[k];
+    }
+    en = 0;
+  };
+
+  for (unsigned base = 0; base < h.count; base += kWave) {
+    const unsigned j = base + lane;
+    bool valid = j < h.count;
+    const unsigned code = valid ? codes[j] : 0u;
+    const int ln = code & 63;
+    const bool sf = (code >> 31) != 0;
+    if (valid) {
+      const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
+      valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
+    }
+    if (what & 0x200u) valid = false;  // profiling ablation
+    int r = PR_FREE;
+    if (valid) {
+      ShapeRef<T> A, B;
+      Pose<T> wa, wb;
+      item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
+      r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
+      if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
+    }
+    const bool ex = r == PR_EXACT;
+    const unsigned long long eb = __ballot(ex);
+    if (eb != 0) {
+      if (en + kWave > kExLds) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        flush();
+      }
+      if (ex) exq[en + lane_rank(eb)] = j;
+      en += __popcll(eb);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  flush();
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool env_hit = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
+  const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
+  const bool lim = (((lane < 32 ? h.limit_lo : h.limit_hi) >> (lane & 31)) & 1u) != 0;
+  unsigned out = lim ? 4u : ((env_hit ? 1u : 0u) | (self_hit ? 2u : 0u));
+  if (redo) out |= kHitRedo;
+  if (cfg < n) W.hit[cfg] = out;
+}
+
+// ---------------------------------------------------------------------------
+// k_narrow2: the exact stage over the dense exact queue (grid-stride)
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256)
+k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
+  const Views<T> V(S);
+  const unsigned total = min(W.pc->exact, W.cap2);
+  const unsigned nthreads = gridDim.x * blockDim.x;
+  const T margin = S.margin;
+  LaneCounters lc{0, 0, 0, 0};
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads) {
+    const unsigned ent = W.exact[e];
+    const size_t wave = ent >> 10;
+    const unsigned j = ent & 1023u;
+    const unsigned code = W.codes[wave * W.cap + j];
+    const size_t cfg = wave * kWave + (code & 63u);
+    const unsigned bit = (code >> 31) ? 2u : 1u;
+    if (W.hit[cfg] & (bit | kHitRedo)) continue;
+    if (what & 0x100u) continue;  // profiling ablation
+    ShapeRef<T> A, B;
+    Pose<T> wa, wb;
+    item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
+    if (pair_stage2<T, false>(A, wa, B, wb, V.verts, V.planes, margin, lc)) atomicOr(&W.hit[cfg], bit);
+  }
+}
+
+}  // namespace gear_hip

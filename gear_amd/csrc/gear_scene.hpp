@@ -130,6 +130,7 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
   for (int k = 0; k < 4; k++) s.lq[k] = T(d.q[k]);
   s.node = node;
   s.v_begin = s.v_count = s.f_begin = s.f_count = 0;
+  s.prism_n = 0;
   auto bad = [&](const char* m) { err = {GH_ERR_INVALID, m}; return false; };
   switch (d.kind) {
     case GH_SHAPE_BOX: {
@@ -167,6 +168,7 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
       std::string why;
       if (!convex_planes(v, tris, planes, why)) { err = {GH_ERR_NONCONVEX, why}; return false; }
       s.kind = SK_MESH;
+      s.prism_n = d.kind == GH_SHAPE_CYLINDER ? 30 : 0;
       s.v_begin = (int)(H.verts.size() / 3);
       s.v_count = (int)(v.size() / 3);
       s.f_begin = (int)(H.planes.size() / 4);

@@ -52,7 +52,8 @@ struct ShapeDev {
   int32_t node;
   int32_t v_begin, v_count;  // mesh vertices  (T[3] each) in the scene's vertex pool
   int32_t f_begin, f_count;  // mesh face planes (nx,ny,nz,offset) in the plane pool
-  int32_t pad[2];
+  int32_t prism_n;  // > 0: the mesh is the regular n-gon prism of urdf.rs:26-50 (vertices: bottom ring, then top ring)
+  int32_t pad;
 };
 
 struct PairDev {

@@ -66,6 +66,11 @@ enum {
 
 /* `what` argument: which predicates to evaluate */
 enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2 };
+/* optional `what` bits that only choose HOW the batch is evaluated; the result
+ * bytes are identical either way (tests/test_gpu_pipeline.py).  Without them
+ * batches of >= 16384 configurations take the multi-kernel pipeline and
+ * smaller ones the single fused kernel.  No counterpart in the reference. */
+enum { GH_PATH_FUSED = 0x1000, GH_PATH_PIPELINE = 0x2000 };
 
 /* ---- descriptors ------------------------------------------------------- */
 

@@ -21,6 +21,7 @@ static int run_pair(const gh_shape_desc* a, const gh_mesh_desc* ma, int nma, con
     ShapeRef<T> r;
     r.kind = s.kind; r.half = {s.half[0], s.half[1], s.half[2]}; r.br = s.br;
     r.vb = s.v_begin; r.vc = s.v_count; r.fb = s.f_begin; r.fc = s.f_count;
+    r.pn = s.prism_n;
     return r;
   };
   Pose<T> wa{{sa.lt[0], sa.lt[1], sa.lt[2]}, {sa.lq[0], sa.lq[1], sa.lq[2], sa.lq[3]}};

@@ -1,0 +1,64 @@
+"""The two evaluation paths of gh_check_batch — the fused kernel (small batches) and the
+sweep / narrow-phase pipeline (large batches) — must return identical flag bytes, and the
+pipeline must match the CPU oracle outside the parity band just like the fused path."""
+import numpy as np
+import pytest
+
+from gear_amd import descriptors as D
+from gear_amd import engine
+from gear_amd import workloads as W
+from oracle import binding as orc
+from tests.parity import compare_flags
+
+pytestmark = pytest.mark.gpu
+
+BOTH = D.GH_CHECK_ENV | D.GH_CHECK_SELF
+
+
+def _workloads(sample_robot, obstacles_robot):
+    pairs = [("root", "l_wrist_yaw"), ("root", "l_wrist_pitch"), ("l_shoulder_yaw", "l_wrist_pitch"),
+             ("root", "l_gripper_linear1"), ("l_shoulder_pitch", "l_gripper_linear2")]
+    return [W.sample_workload(sample_robot, obstacles_robot, 0.01, self_pairs=pairs), W.metric_workload(),
+            W.ur10_workload(96), W.sawyer_workload(1024)]
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_pipeline_equals_fused(sample_robot, obstacles_robot, prec):
+    for w in _workloads(sample_robot, obstacles_robot):
+        hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+        n = 6000 if w.obstacle_keep.desc.n_shapes > 512 else 40000
+        q = w.configs(n, seed=21, dtype=hip.dtype, overshoot=0.02)
+        for what in (BOTH, D.GH_CHECK_ENV, D.GH_CHECK_SELF):
+            a = hip.check_batch(q, what | D.GH_PATH_FUSED)
+            b = hip.check_batch(q, what | D.GH_PATH_PIPELINE)
+            assert (a == b).all(), (w.name, prec, what, int((a != b).sum()))
+        assert ((a | b) != 0).any()
+        # ragged sizes around the wavefront width, through the pipeline
+        for m in (1, 63, 64, 65, 129):
+            assert (hip.check_batch(q[:m], BOTH | D.GH_PATH_PIPELINE) ==
+                    hip.check_batch(q[:m], BOTH | D.GH_PATH_FUSED)).all()
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_pipeline_matches_oracle(prec):
+    w = W.metric_workload()
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    q = w.configs(3000, seed=22, dtype=hip.dtype, overshoot=0.01)
+    got = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE)
+    want, band = ora.check(q, BOTH, threads=16)
+    rep = compare_flags(got, want, band, prec)
+    print(prec, rep)
+    assert rep["outside"] == 0, rep
+
+
+def test_pipeline_queue_overflow_is_rechecked():
+    """A scene so dense that a wave's survivor region (1024 items) overflows: those waves are
+    re-checked by the fused kernel, so the flags still equal the fused path's."""
+    w = W.Workload("dense", W.arm7_robot(), W.obstacle_field(2048, 3, ("box", "ball"), (0.5, 0.5), cube=1.6),
+                   0.01, W.ARM7_SELF_PAIRS)
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    q = w.configs(4096, seed=23)
+    a = hip.check_batch(q, BOTH | D.GH_PATH_FUSED)
+    b = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE)
+    assert (a == b).all()
