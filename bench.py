@@ -30,6 +30,20 @@ from gear_amd import workloads as W
 
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+PIPE_MIN = 1 << 14                          # gear_hip.hip kPipeMin: batches below it take the fused kernel alone
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "pipeline_traffic.json")   # tools/pmc_traffic.py
+
+
+def measured_traffic(batch):
+    """Fabric bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, gfx950 correction applied; tools/pmc_traffic.py), scaled to this batch.  None when
+    the summary is absent: bench.py itself cannot run under the profiler."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        return float(t["total_bytes_per_config"]) * batch
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def algorithmic_flops_per_config(w, counters):
@@ -197,12 +211,20 @@ def main():
                        "batch_per_gpu": B, "checks": "env+self+limit", "sharding": f"dp{world}, scene replicated",
                        "collectives": "all_gather(flags) per step" if world > 1 else "none"},
             "roofline": {
-                "bound": "valu", "kernel": "k_check", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved_tflops / peak, "traffic": None,
+                "bound": "valu",
+                "kernel": ("k_sweep + k_narrow1 + k_narrow2 + k_check(finalize), one launch of each per 1M-config chunk"
+                           if B >= PIPE_MIN else "k_check (fused)"),
+                "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved_tflops / peak, "traffic": measured_traffic(B) if args.precision == 32 else None,
+                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r01/pipeline_traffic.json)",
+                "algorithmic_bytes": bytes_per_config * B,
                 "kernel_ms": kernel_ms, "algorithmic_flops_per_config": flops_per_config, "mix": mix,
                 "hbm_algorithmic_GBps": bytes_per_config * B / (kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
-                "note": "VALU-bound path (SURVEY 8d): the f32 vector peak equals the f32 MFMA peak; MFMA unused by design"},
+                "sustained_fma_TFLOPs_measured": {"3_waves_per_simd": 111.9, "8_waves_per_simd": 129.9,
+                                                  "source": "tools/valu_rate.hip, profiles/r01/valu_rate.txt"},
+                "note": "VALU-bound path (SURVEY 8d): the f32 vector peak equals the f32 MFMA peak; MFMA unused by "
+                        "design.  kernel_ms = HIP events on the launch stream around one step (all kernels of the step)"},
             "flag_rates": {"env": stats[0].item() / (B * world), "self": stats[1].item() / (B * world),
                            "limit": stats[2].item() / (B * world)},
             "parity_spot_check": parity,

@@ -19,7 +19,7 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-Wall", "-Wno-unused-function", "-o", LIB_PATH, SOURCES[0]]
+               "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-o", LIB_PATH, SOURCES[0]]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -79,18 +79,23 @@ template <class T> GD Pose<T> pose_mul(const Pose<T>& a, const Pose<T>& b) {
 }
 
 // One step of k::Chain::update_transforms: world = parent * (origin * joint(q)).
+// (s, c) = sin, cos of position / 2 for a revolute joint (unused otherwise).
 template <class T>
-GD Pose<T> fk_step(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position) {
+GD Pose<T> fk_step_sc(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position, T s, T c) {
   Pose<T> local{ot, oq};
   if (joint_type == JT_ROT) {
-    T s, c;
-    t_sincos(position / T(2), &s, &c);
     Q4<T> jq{axis.x * s, axis.y * s, axis.z * s, c};
     local.r = qmul(oq, jq);
   } else if (joint_type == JT_LIN) {
     local.t = ot + qrot(oq, axis * position);
   }
   return pose_mul(parent, local);
+}
+template <class T>
+GD Pose<T> fk_step(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position) {
+  T s = T(0), c = T(1);
+  if (joint_type == JT_ROT) t_sincos(position / T(2), &s, &c);
+  return fk_step_sc(parent, ot, oq, axis, joint_type, position, s, c);
 }
 #pragma clang fp contract(fast)
 
@@ -355,6 +360,17 @@ GD bool inside_with_clearance(const ShapeRef<T>& P, const ShapeRef<T>& X, const 
                               VP verts, PP planes, T m) {
   if (X.br > T(2) * P.br) return false;  // enclosing-ball argument: X inside P needs br(X) <= 2 br(P)
   T xr = X.kind == SK_BALL ? X.half.x : T(0);
+  // cheap necessary condition first, for the kinds whose frame origin is a point of their core (box,
+  // ball, prism; a general mesh's bounding-box centre need not be): that point must clear every face
+  // by m + xr.  Most intersecting pairs fail it, and it needs no support evaluation.
+  if (X.kind != SK_MESH || X.pn > 0) {
+    const V3<T> cx = p_is_a ? rel.t : -rel_tmul(rel, rel.t);  // X's origin in P's frame
+    for (int f = 0; f < P.fc; f++) {
+      V3<T> n{planes[4 * (P.fb + f)], planes[4 * (P.fb + f) + 1], planes[4 * (P.fb + f) + 2]};
+      if (!(planes[4 * (P.fb + f) + 3] - dot(n, cx) - xr >= m)) return false;
+    }
+    if (X.kind == SK_BALL) return true;  // a ball's core is its centre: the loop above was the whole test
+  }
   for (int f = 0; f < P.fc; f++) {
     V3<T> n{planes[4 * (P.fb + f)], planes[4 * (P.fb + f) + 1], planes[4 * (P.fb + f) + 2]};
     T o = planes[4 * (P.fb + f) + 3];
@@ -383,16 +399,8 @@ enum : int { PR_FREE = 0, PR_HIT = 1, PR_EXACT = 2 };
 template <class T, bool COUNT>
 GD int pair_stage1(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B, const Pose<T>& wb, T margin,
                    LaneCounters& lc) {
-  if (A.kind == SK_MESH || B.kind == SK_MESH) {
-    // a mesh carries the half extents of its local bounding box in `half` (a ball: the cube around it):
-    // boxes that are >= margin apart prove the shapes are; anything closer goes to the exact stage
-    if (!(T(0) < margin)) return PR_FREE;
-    Rel<T> rel = make_rel(wa, wb);
-    V3<T> ha = A.kind == SK_BALL ? V3<T>{A.half.x, A.half.x, A.half.x} : A.half;
-    V3<T> hb = B.kind == SK_BALL ? V3<T>{B.half.x, B.half.x, B.half.x} : B.half;
-    if (COUNT) lc.sat_tests++;
-    return sat_box_box(ha, hb, rel, margin) == 0 ? PR_FREE : PR_EXACT;
-  }
+  const bool mesh = A.kind == SK_MESH || B.kind == SK_MESH;
+  if (mesh && !(T(0) < margin)) return PR_FREE;
   if (A.kind == SK_BALL && B.kind == SK_BALL) {
     // distance_ball_ball, verbatim semantics
     V3<T> d = wa.t - wb.t;
@@ -401,20 +409,27 @@ GD int pair_stage1(const ShapeRef<T>& A, const Pose<T>& wa, const ShapeRef<T>& B
     return dist < margin ? PR_HIT : PR_FREE;
   }
   Rel<T> rel = make_rel(wa, wb);
-  if (A.kind == SK_BOX && B.kind == SK_BOX) {
-    if (COUNT) lc.sat_tests++;
-    int r = sat_box_box(A.half, B.half, rel, margin);
-    if (r == 2) return PR_EXACT;
-    return (r == 1 && T(0) < margin) ? PR_HIT : PR_FREE;
+  if (!mesh && (A.kind == SK_BALL || B.kind == SK_BALL)) {
+    // ball vs box: point-to-box distance in the box's frame
+    V3<T> p, h;
+    T r;
+    if (A.kind == SK_BOX) { p = rel.t; h = A.half; r = B.half.x; }
+    else { p = -rel_tmul(rel, rel.t); h = B.half; r = A.half.x; }
+    V3<T> e{t_max(t_abs(p.x) - h.x, T(0)), t_max(t_abs(p.y) - h.y, T(0)), t_max(t_abs(p.z) - h.z, T(0))};
+    T dist = t_max(t_sqrt(dot(e, e)) - r, T(0));
+    return dist < margin ? PR_HIT : PR_FREE;
   }
-  // ball vs box: point-to-box distance in the box's frame
-  V3<T> p, h;
-  T r;
-  if (A.kind == SK_BOX) { p = rel.t; h = A.half; r = B.half.x; }
-  else { p = -rel_tmul(rel, rel.t); h = B.half; r = A.half.x; }
-  V3<T> e{t_max(t_abs(p.x) - h.x, T(0)), t_max(t_abs(p.y) - h.y, T(0)), t_max(t_abs(p.z) - h.z, T(0))};
-  T dist = t_max(t_sqrt(dot(e, e)) - r, T(0));
-  return dist < margin ? PR_HIT : PR_FREE;
+  // One separating-axis evaluation serves both remaining cases (a single site: lanes of a wavefront
+  // hold different pair kinds).  box vs box: decisive unless the best axis shows a gap in [0, margin).
+  // A mesh carries the half extents of its local bounding box in `half` (a ball: the cube around it):
+  // boxes that are >= margin apart prove the shapes are; anything closer goes to the exact stage.
+  V3<T> ha = A.kind == SK_BALL ? V3<T>{A.half.x, A.half.x, A.half.x} : A.half;
+  V3<T> hb = B.kind == SK_BALL ? V3<T>{B.half.x, B.half.x, B.half.x} : B.half;
+  if (COUNT) lc.sat_tests++;
+  const int r = sat_box_box(ha, hb, rel, margin);
+  if (mesh) return r == 0 ? PR_FREE : PR_EXACT;
+  if (r == 2) return PR_EXACT;
+  return (r == 1 && T(0) < margin) ? PR_HIT : PR_FREE;
 }
 
 // Stage 2: GJK margin query on the convex cores (ball radii folded into the

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,6 +65,7 @@ struct DevBuf {
 struct gh_scene {
   int precision = 32, device = 0;
   int D = 0, N = 0, L = 0, O = 0, P = 0, n_slots = 0;
+  int max_shape_node = -1;  // last node that owns a robot shape
   double margin = 0;
   SceneDev<float> s32{};
   SceneDev<double> s64{};
@@ -109,8 +111,8 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.rshapes, &S.rshapes))) return rc;
   if ((rc = upload(sc, H.oshapes, &S.oshapes))) return rc;
   if ((rc = upload(sc, H.ocull, &S.ocull))) return rc;
-  if ((rc = upload(sc, H.ocull8, &S.ocull8))) return rc;
-  S.n_obs_pad = (int)(H.ocull8.size() / 5);
+  if ((rc = upload(sc, H.ocullq, &S.ocullq))) return rc;
+  S.n_obs_pad = (int)(H.ocullq.size() / 5);
   if ((rc = upload(sc, H.pairs, &S.pairs))) return rc;
   if ((rc = upload(sc, H.spairs, &S.spairs))) return rc;
   if ((rc = upload(sc, H.spair_r, &S.spair_r))) return rc;
@@ -119,6 +121,7 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
   sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
   sc->n_slots = S.n_slots;
+  sc->max_shape_node = H.rshapes.empty() ? -1 : H.rshapes.back().node;
   return GH_OK;
 }
 
@@ -198,20 +201,30 @@ void launch_check(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, ui
 }
 
 // ---- the pipeline (gear_pipeline.hpp) ------------------------------------------------------------
-constexpr size_t kPipeChunk = size_t(1) << 19;  // configurations per pipeline pass
+constexpr size_t kPipeChunkDefault = size_t(1) << 20;  // configurations per pipeline pass
+size_t pipe_chunk() {  // GEAR_HIP_PIPE_CHUNK overrides (tuning aid)
+  static const size_t v = [] {
+    const char* e = getenv("GEAR_HIP_PIPE_CHUNK");
+    size_t x = e ? (size_t)strtoull(e, nullptr, 0) : 0;
+    if (x < 4096 || x > (size_t(1) << 24)) x = kPipeChunkDefault;
+    return (x + kWave - 1) / kWave * kWave;
+  }();
+  return v;
+}
 constexpr size_t kPipeMin = size_t(1) << 14;    // smaller batches take the fused kernel alone
 constexpr uint32_t kForceFused = 0x1000u, kForcePipe = 0x2000u;  // `what` bits for tests and profiling
 
 template <class T, int K>
 void launch_sweep_k(const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, const PipeWs<T>& W, int lds_centres,
-                    size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((k_sweep<T, K>), dim3(grid_for(cnt)), dim3(kWave), lds, st, S, q, cnt, what, W, lds_centres);
+                    int max_node, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_sweep<T, K>), dim3(grid_for(cnt)), dim3(kWave), lds, st, S, q, cnt, what, W, lds_centres,
+                     max_node);
 }
 
 template <class T>
 int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags,
                  hipStream_t st) {
-  const size_t chunk = std::min((n + kWave - 1) / kWave * kWave, kPipeChunk);
+  const size_t chunk = std::min((n + kWave - 1) / kWave * kWave, pipe_chunk());
   const size_t waves = chunk / kWave;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
   PipeWs<T> W{};
@@ -243,18 +256,20 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const size_t slot_bytes = (size_t)S.n_slots * 7 * kWave * sizeof(T);
   const size_t cen_bytes = (size_t)S.n_shapes * 3 * kWave * sizeof(T);
   const int lds_centres = do_self && cen_bytes <= 24 * 1024;
-  const size_t lds = slot_bytes + (lds_centres ? cen_bytes : 0);
+  const int max_node = sc->max_shape_node;  // the walk stops at the last node that carries a shape
+  const size_t sc_bytes = (size_t)(max_node + 1) * 2 * kWave * sizeof(T);
+  const size_t lds = slot_bytes + sc_bytes + (lds_centres ? cen_bytes : 0);
   const int K = pick_chunk(sc->L);
   for (size_t off = 0; off < n; off += chunk) {
     const size_t cnt = std::min(chunk, n - off);
     const T* qc = q + off * sc->D;
     GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), st));
     switch (K) {
-      case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, lds, st); break;
-      case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, lds, st); break;
-      default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, lds, st); break;
+      case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+      case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+      default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
     }
-    hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kWave), 0, st, S, cnt, what, W);
+    hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kN1Threads), 0, st, S, cnt, what, W);
     const unsigned g2 = (unsigned)std::min<size_t>(2048, (cnt + 255) / 256);
     hipLaunchKernelGGL((k_narrow2<T>), dim3(g2), dim3(256), 0, st, S, what, W);
     launch_check<T>(sc, S, qc, cnt, what, flags + off, st, false, plan, gs, gstride, W.hit);
@@ -266,7 +281,8 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
 int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted) {
   if (!(sc->margin > 0)) what &= ~3u;  // distance >= 0 is never < a non-positive margin: only limits can fail
   const size_t slot_bytes = (size_t)sc->n_slots * 7 * kWave * sc->elem();
-  const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 && slot_bytes <= 32 * 1024;
+  const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 &&
+                       slot_bytes + (size_t)(sc->max_shape_node + 1) * 2 * kWave * sc->elem() <= 32 * 1024;
   if (pipe_ok && !(what & kForceFused) && (n >= kPipeMin || (what & kForcePipe))) {
     if (n == 0) return GH_OK;
     return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st)

@@ -36,7 +36,7 @@ template <class T> struct Views {
   const GEAR_CAS ShapeDev<T>* rshapes;
   const GEAR_CAS ShapeDev<T>* oshapes;
   const GEAR_CAS T* ocull;
-  const GEAR_CAS T* ocull8;
+  const GEAR_CAS T* ocullq;
   const GEAR_CAS PairDev* pairs;
   const GEAR_CAS int32_t* spairs;
   const GEAR_CAS T* spair_r;
@@ -44,7 +44,7 @@ template <class T> struct Views {
   const GEAR_CAS T* planes;
   __device__ explicit Views(const SceneDev<T>& S)
       : nodes(to_cas(S.nodes)), limits(to_cas(S.limits)), rshapes(to_cas(S.rshapes)), oshapes(to_cas(S.oshapes)),
-        ocull(to_cas(S.ocull)), ocull8(to_cas(S.ocull8)), pairs(to_cas(S.pairs)), spairs(to_cas(S.spairs)),
+        ocull(to_cas(S.ocull)), ocullq(to_cas(S.ocullq)), pairs(to_cas(S.pairs)), spairs(to_cas(S.spairs)),
         spair_r(to_cas(S.spair_r)), verts(to_cas(S.verts)), planes(to_cas(S.planes)) {}
 };
 
@@ -95,19 +95,34 @@ template <class T> __device__ bool limits_ok(const SceneDev<T>& S, const Views<T
   return ok;
 }
 
-// world pose of node k given the walk state; updates `cur`
-template <class T>
-__device__ void node_world(const Views<T>& V, int k, const T* qrow, const PoseStore<T>& st, Pose<T>& cur) {
+// joint position of node k for this lane's configuration
+template <class T> __device__ __forceinline__ T node_position(const GEAR_CAS NodeDev<T>* nd, const T* qrow) {
+  T pos = nd->const_pos;
+  int col = nd->col;
+  if (col >= 0) pos = joint_value(qrow[col], nd->direct, nd->mult, nd->off);
+  return pos;
+}
+
+// world pose of node k given the walk state; updates `cur`.  SC: sin/cos of the half angle were
+// computed ahead of the walk and sit at sc[(2k) * 64 + lane], sc[(2k + 1) * 64 + lane].
+template <class T, bool SC = false>
+__device__ void node_world(const Views<T>& V, int k, const T* qrow, const PoseStore<T>& st, Pose<T>& cur,
+                           const T* sc = nullptr) {
   const GEAR_CAS NodeDev<T>* nd = V.nodes + k;
   Pose<T> parent = cur;
   int ps = nd->parent_slot;
   if (ps == PARENT_IDENTITY) parent = {{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
   else if (ps >= 0) parent = st.get(ps);
-  T pos = nd->const_pos;
-  int col = nd->col;
-  if (col >= 0) pos = joint_value(qrow[col], nd->direct, nd->mult, nd->off);
-  cur = fk_step(parent, V3<T>{nd->ot[0], nd->ot[1], nd->ot[2]}, Q4<T>{nd->oq[0], nd->oq[1], nd->oq[2], nd->oq[3]},
-                V3<T>{nd->axis[0], nd->axis[1], nd->axis[2]}, nd->joint_type, pos);
+  const T pos = node_position(nd, qrow);
+  const V3<T> ot{nd->ot[0], nd->ot[1], nd->ot[2]}, axis{nd->axis[0], nd->axis[1], nd->axis[2]};
+  const Q4<T> oq{nd->oq[0], nd->oq[1], nd->oq[2], nd->oq[3]};
+  if (SC) {
+    T s = T(0), c = T(1);
+    if (nd->joint_type == JT_ROT) { s = sc[(2 * k) * kWave]; c = sc[(2 * k + 1) * kWave]; }
+    cur = fk_step_sc(parent, ot, oq, axis, nd->joint_type, pos, s, c);
+  } else {
+    cur = fk_step(parent, ot, oq, axis, nd->joint_type, pos);
+  }
   int ss = nd->save_slot;
   if (ss >= 0) st.put(ss, cur);
 }
@@ -154,27 +169,6 @@ template <class T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.2e-7f; };
 template <> struct Eps<double> { static constexpr double v = 2.3e-16; };
 
-// 8 obstacles' cull records (40 scalars, wave-uniform -> SGPRs)
-template <class T> struct CullBlock {
-  T v[40];
-  template <class P> GD void load(P p) {
-#pragma unroll
-    for (int i = 0; i < 40; i++) v[i] = p[i];
-  }
-  GD unsigned sweep(unsigned m, V3<T> c, T rho, T a0) const {
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      T t = a0 + v[32 + k];
-      t = t_fma(v[k], c.x, t);
-      t = t_fma(v[8 + k], c.y, t);
-      t = t_fma(v[16 + k], c.z, t);
-      t = t_fma(v[24 + k], rho, t);
-      m = __builtin_amdgcn_alignbit(m, sign_bits(t), 31);  // m = (m << 1) | (t < 0)
-    }
-    return m;
-  }
-};
-
 template <class T> struct WaveStore {
   T* base;
   size_t stride, col0;  // column of lane l = col0 + l
@@ -205,28 +199,39 @@ template <bool GSTORE> __device__ __forceinline__ void wave_sync() {
 // in flight while the previous block is being used.  (Scalar loads return out of order, so the only
 // wait there is is "all outstanding loads": a second load in flight would be waited for as soon as
 // the first one's data is needed.)
-// One obstacle block against K shapes.  For a fixed obstacle the K shapes are K independent chains
+// Half a cull block: 4 obstacles' records, 20 scalars [5][4] (wave-uniform -> SGPRs).  Two of them
+// are 40 SGPRs, which leaves the rest of the scalar file to the kernel (two 8-obstacle blocks do not:
+// the compiler then parks prefetched records in VGPR lanes, one VALU op per scalar each way).
+template <class T> struct CullQuad {
+  T v[20];
+  template <class P> GD void load(P p) {
+#pragma unroll
+    for (int i = 0; i < 20; i++) v[i] = p[i];
+  }
+};
+
+// Four obstacles against K shapes.  For a fixed obstacle the K shapes are K independent chains
 // (add, 4 fma, alignbit), issued stage by stage so that dependent instructions sit K slots apart.
 template <class T, int K>
-__device__ __forceinline__ void sweep_block(const CullBlock<T>& b, const V3<T> (&c)[K], const T (&rho)[K],
-                                            const T (&a0)[K], unsigned (&m)[K]) {
+__device__ __forceinline__ void sweep_quad(const CullQuad<T>& b, const V3<T> (&c)[K], const T (&rho)[K],
+                                           const T (&a0)[K], unsigned (&m)[K]) {
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < 4; k++) {
     T t[K];
 #pragma unroll
-    for (int j = 0; j < K; j++) t[j] = a0[j] + b.v[32 + k];
+    for (int j = 0; j < K; j++) t[j] = a0[j] + b.v[16 + k];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < K; j++) t[j] = t_fma(b.v[k], c[j].x, t[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[8 + k], c[j].y, t[j]);
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[4 + k], c[j].y, t[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[16 + k], c[j].z, t[j]);
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[8 + k], c[j].z, t[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[24 + k], rho[j], t[j]);
+    for (int j = 0; j < K; j++) t[j] = t_fma(b.v[12 + k], rho[j], t[j]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < K; j++) m[j] = __builtin_amdgcn_alignbit(m[j], sign_bits(t[j]), 31);  // m = (m << 1) | (t < 0)
@@ -234,26 +239,27 @@ __device__ __forceinline__ void sweep_block(const CullBlock<T>& b, const V3<T> (
   }
 }
 
-// Sweep of K robot shapes against 32 obstacles (4 blocks of 8).  Obstacle blocks are the outer loop and
-// the K shapes the inner one: a block's 40 scalars feed 48*K VALU ops, and exactly ONE block load is
-// in flight while the previous block is being used.  (Scalar loads return out of order, so the only
+// Sweep of K robot shapes against 32 obstacles (8 quads).  Obstacle records are the outer loop and
+// the K shapes the inner one: a quad's 20 scalars feed 24*K VALU ops, and exactly ONE quad load is
+// in flight while the previous quad is being used.  (Scalar loads return out of order, so the only
 // wait there is is "all outstanding loads": a second load in flight would be waited for as soon as
 // the first one's data is needed.)
 template <class T, int K>
 __device__ __forceinline__ void sweep_unit(const GEAR_CAS T* rec, const V3<T> (&c)[K], const T (&rho)[K],
                                            const T (&a0)[K], unsigned (&m)[K]) {
-  CullBlock<T> A, B;
+  CullQuad<T> A, B;
 #pragma unroll
   for (int j = 0; j < K; j++) m[j] = 0u;
   A.load(rec);
-  __builtin_amdgcn_sched_barrier(0);
-  B.load(rec + 40);
-  sweep_block<T, K>(A, c, rho, a0, m);
-  A.load(rec + 80);
-  sweep_block<T, K>(B, c, rho, a0, m);
-  B.load(rec + 120);
-  sweep_block<T, K>(A, c, rho, a0, m);
-  sweep_block<T, K>(B, c, rho, a0, m);
+#pragma unroll
+  for (int h = 0; h < 8; h += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    B.load(rec + 20 * (h + 1));
+    sweep_quad<T, K>(A, c, rho, a0, m);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h + 2 < 8) A.load(rec + 20 * (h + 2));
+    sweep_quad<T, K>(B, c, rho, a0, m);
+  }
 }
 
 constexpr size_t queue_bytes(int K) { return (size_t)(kQCap + kGCap + 4 + K * kWave) * 4; }
@@ -354,7 +360,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
 #pragma unroll
         for (int j = 0; j < K; j++) m[j] = 0u;
       } else {
-        sweep_unit<T, K>(V.ocull8 + (size_t)5 * o0, c, rho, a0, m);
+        sweep_unit<T, K>(V.ocullq + (size_t)5 * o0, c, rho, a0, m);
       }
 #pragma unroll
       for (int j = 0; j < K; j++) mst[j * kWave + lane] = m[j];

@@ -27,7 +27,7 @@
 
 namespace gear_hip {
 
-constexpr int kExLds = 192;           // per-workgroup staging of exact entries in k_narrow1
+constexpr int kExLds = 512;           // per-workgroup staging of exact entries in k_narrow1
 constexpr int kMaxItemCap = 1024;     // an exact entry packs the item index into 10 bits
 
 struct WaveHdr {
@@ -85,7 +85,7 @@ __device__ __forceinline__ void wave_offsets(unsigned nl, unsigned& off, unsigne
 // ---------------------------------------------------------------------------
 template <class T, int K>
 __global__ void __launch_bounds__(kWave)
-k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres) {
+k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres, int max_node) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
   const int lane = threadIdx.x;
@@ -95,7 +95,10 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
   const size_t i = live ? col : n - 1;
   const T* qrow = q + i * (size_t)S.n_cols;
   const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)lane};
-  T* cen = reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T));  // [L][3][64] when lds_centres
+  // half-angle sin/cos of every node, computed ahead of the walk: the f64-rounded sincos of the f32
+  // path needs far more registers than the walk, and must not be live together with the K poses
+  T* sc = reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T)) + lane;  // [N][2][64]
+  T* cen = sc - lane + (size_t)(max_node + 1) * 2 * kWave;  // [L][3][64] when lds_centres
 
   const bool ok = limits_ok(S, V, qrow);
   const bool do_env = (what & 1u) && S.n_obs > 0;
@@ -120,18 +123,31 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
   int fill = 0, node = -1;
   Pose<T> cur{{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
   const int n_walk = (do_env || do_self) ? S.n_shapes : 0;
+  const bool lazy_store = do_self && lds_centres && S.n_shapes <= K;  // P[j] is shape j's pose after the walk
+  if (n_walk > 0) {
+    for (int k = 0; k <= max_node; k++) {
+      const GEAR_CAS NodeDev<T>* nd = V.nodes + k;
+      if (nd->joint_type != JT_ROT) continue;
+      T sn, cs;
+      t_sincos(node_position(nd, qrow) / T(2), &sn, &cs);
+      sc[(2 * k) * kWave] = sn;
+      sc[(2 * k + 1) * kWave] = cs;
+    }
+  }
 
   for (int s = 0; s < n_walk; s++) {
     const GEAR_CAS ShapeDev<T>* sh = V.rshapes + s;
     const int target = sh->node;
     while (node < target) {
       node++;
-      node_world(V, node, qrow, slots, cur);
+      node_world<T, true>(V, node, qrow, slots, cur, sc);
     }
     const Pose<T> ws = pose_mul(cur, shape_pose<T>(sh));
     if (do_self) {
-      T* b = W.pstore + (size_t)s * 7 * W.stride + col;
-      if (live) {
+      // a robot whose shapes all fit the K register slots stores only the poses its self survivors
+      // need (after the self sweep, below); a larger one stores every pose here
+      if (live && !lazy_store) {
+        T* b = W.pstore + (size_t)s * 7 * W.stride + col;
         b[0] = ws.t.x; b[W.stride] = ws.t.y; b[2 * W.stride] = ws.t.z;
         b[3 * W.stride] = ws.r.i; b[4 * W.stride] = ws.r.j; b[5 * W.stride] = ws.r.k; b[6 * W.stride] = ws.r.w;
       }
@@ -140,7 +156,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
         cc[0] = ws.t.x; cc[kWave] = ws.t.y; cc[2 * kWave] = ws.t.z;
       }
     }
-    if (!do_env) continue;
+    if (!do_env && !lazy_store) continue;
     {
       T r = sh->br;
       asm volatile("" : "+v"(r));  // the radius in a VGPR: the obstacle record supplies the SGPR operand
@@ -152,6 +168,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
       fill++;
     }
     if (fill < K && s != n_walk - 1) continue;
+    if (!do_env) { fill = lazy_store ? fill : 0; continue; }
 
     // ---- sweep the `fill` shapes s0 .. s against every obstacle ----------------
     const int s0 = s + 1 - fill;
@@ -164,7 +181,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
 #pragma unroll
         for (int j = 0; j < K; j++) m[j] = 0u;
       } else {
-        sweep_unit<T, K>(V.ocull8 + (size_t)5 * o0, c, rho, a0, m);
+        sweep_unit<T, K>(V.ocullq + (size_t)5 * o0, c, rho, a0, m);
       }
       unsigned nl = 0;
 #pragma unroll
@@ -200,6 +217,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
 
   // ---- self shape pairs ---------------------------------------------------------
   if (do_self) {
+    unsigned need = 0;  // lazy_store: bit j set when shape j's pose must reach the pose store
     if (!lds_centres) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores -> own loads of the pose store
     for (int p0 = 0; p0 < S.n_spairs; p0 += 32) {
       const int cnt = min(32, S.n_spairs - p0);
@@ -225,6 +243,12 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
       if (dbg_no_push) m = 0;
       const unsigned nl = (unsigned)__popc(m);
       if (__ballot(nl != 0) == 0) continue;
+      if (lazy_store) {
+        for (int k = 0; k < cnt; k++) {  // shapes whose pose a survivor of this lane needs
+          const unsigned both = (1u << V.spairs[4 * (p0 + k)]) | (1u << V.spairs[4 * (p0 + k) + 1]);
+          need |= (m & (0x80000000u >> k)) ? both : 0u;
+        }
+      }
       unsigned off, tot;
       wave_offsets(nl, off, tot);
       if (count + tot > W.cap) {
@@ -238,6 +262,16 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
         }
       }
       count += tot;
+    }
+    if (lazy_store) {
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        if ((need >> j) & 1u) {
+          T* b = W.pstore + (size_t)j * 7 * W.stride + col;
+          b[0] = P[j].t.x; b[W.stride] = P[j].t.y; b[2 * W.stride] = P[j].t.z;
+          b[3 * W.stride] = P[j].r.i; b[4 * W.stride] = P[j].r.j; b[5 * W.stride] = P[j].r.k; b[6 * W.stride] = P[j].r.w;
+        }
+      }
     }
   }
 
@@ -271,46 +305,38 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
 }
 
 // ---------------------------------------------------------------------------
-// k_narrow1: workgroup (one wavefront) b handles the items of sweep wave b
+// k_narrow1: workgroup b (4 wavefronts) handles the items of sweep wave b, one item per lane.
+// Four waves per region, not one: an item is a chain of dependent loads (code -> shape records ->
+// poses) in front of ~700 VALU ops, and the rounds of one wave run back to back.
 // ---------------------------------------------------------------------------
+constexpr int kN1Threads = 256;
+
 template <class T>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kN1Threads)
 k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
-  __shared__ unsigned hits[4];       // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
-  __shared__ unsigned exq[kExLds];   // staged exact entries
+  __shared__ unsigned hits[4];      // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
+  __shared__ unsigned exq[kExLds];  // staged exact entries
+  __shared__ unsigned en;           // fill of exq
+  __shared__ unsigned ebase;
   const Views<T> V(S);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const size_t wave = blockIdx.x;
   const WaveHdr h = W.hdr[wave];
-  const size_t cfg = wave * kWave + lane;
   if (h.overflow) {  // the region ran full: the fused path re-checks these configurations
-    if (cfg < n) W.hit[cfg] = kHitRedo;
+    const size_t cfg = wave * kWave + tid;
+    if (tid < kWave && cfg < n) W.hit[cfg] = kHitRedo;
     return;
   }
-  if (lane < 4) hits[lane] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  if (tid < 4) hits[tid] = 0;
+  if (tid == 4) en = 0;
+  __syncthreads();
   const unsigned* codes = W.codes + wave * W.cap;
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
-  int en = 0;          // wave-uniform fill of exq
-  bool redo = false;   // the exact queue ran full
+  bool redo = false;  // the exact queue ran full (uniform over the workgroup)
 
-  auto flush = [&]() {
-    if (en == 0) return;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&W.pc->exact, (unsigned)en);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base + (unsigned)en > W.cap2) {
-      redo = true;
-    } else {
-      for (int k = lane; k < en; k += kWave) W.exact[base + k] = ((unsigned)wave << 10) | exq[k];
-    }
-    en = 0;
-  };
-
-  for (unsigned base = 0; base < h.count; base += kWave) {
-    const unsigned j = base + lane;
+  for (unsigned base = 0; base < h.count; base += kN1Threads) {
+    const unsigned j = base + tid;
     bool valid = j < h.count;
     const unsigned code = valid ? codes[j] : 0u;
     const int ln = code & 63;
@@ -328,29 +354,41 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
       if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
     }
+    // stage the undecided items; when the staging area cannot take another full round, move it to
+    // the global exact queue with one atomic for the whole workgroup
     const bool ex = r == PR_EXACT;
     const unsigned long long eb = __ballot(ex);
+    unsigned slot = 0;
     if (eb != 0) {
-      if (en + kWave > kExLds) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        flush();
-      }
-      if (ex) exq[en + lane_rank(eb)] = j;
-      en += __popcll(eb);
+      if ((tid & 63) == (int)__builtin_ctzll(eb)) slot = atomicAdd(&en, (unsigned)__popcll(eb));
+      slot = __shfl(slot, (int)__builtin_ctzll(eb)) + lane_rank(eb);
+      if (ex) exq[slot] = j;  // en <= kExLds - kN1Threads held before this round
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (en + kN1Threads > kExLds || base + kN1Threads >= h.count) {
+      const unsigned cnt = en;
+      if (cnt != 0) {
+        if (tid == 0) ebase = atomicAdd(&W.pc->exact, cnt);
+        __syncthreads();
+        if (ebase + cnt > W.cap2) redo = true;
+        else
+          for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[ebase + k] = ((unsigned)wave << 10) | exq[k];
+        __syncthreads();
+        if (tid == 0) en = 0;
+        __syncthreads();
+      }
+    }
   }
-  flush();
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const bool env_hit = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
-  const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
-  const bool lim = (((lane < 32 ? h.limit_lo : h.limit_hi) >> (lane & 31)) & 1u) != 0;
-  unsigned out = lim ? 4u : ((env_hit ? 1u : 0u) | (self_hit ? 2u : 0u));
-  if (redo) out |= kHitRedo;
-  if (cfg < n) W.hit[cfg] = out;
+  __syncthreads();
+  if (tid < kWave) {
+    const size_t cfg = wave * kWave + tid;
+    const bool env_hit = ((hits[tid >> 5] >> (tid & 31)) & 1u) != 0;
+    const bool self_hit = ((hits[2 + (tid >> 5)] >> (tid & 31)) & 1u) != 0;
+    const bool lim = (((tid < 32 ? h.limit_lo : h.limit_hi) >> (tid & 31)) & 1u) != 0;
+    unsigned out = lim ? 4u : ((env_hit ? 1u : 0u) | (self_hit ? 2u : 0u));
+    if (redo) out |= kHitRedo;
+    if (cfg < n) W.hit[cfg] = out;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -26,7 +26,7 @@ struct HostTables {
   std::vector<NodeDev<T>> nodes;
   std::vector<LimitDev<T>> limits;
   std::vector<ShapeDev<T>> rshapes, oshapes;
-  std::vector<T> ocull, ocull8;
+  std::vector<T> ocull, ocullq;
   std::vector<PairDev> pairs;
   std::vector<int32_t> spairs;  // flattened self shape pairs: [n][4] = s1, s2, node-pair index, 0
   std::vector<T> spair_r;       // [n] bounding radii sum + margin, inflated
@@ -327,10 +327,10 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
   }
   // far dummies pad the sweep to whole groups of 32: k is huge and positive, the test value never goes negative
   while (cull_rec.size() % 32 != 0) cull_rec.push_back({0, 0, 0, 0, 1e30});
-  // blocks of 8 obstacles, component-major inside a block: [block][5][8]
-  H.ocull8.assign(cull_rec.size() * 5, T(0));
+  // quads of 4 obstacles, component-major inside a quad: [quad][5][4]
+  H.ocullq.assign(cull_rec.size() * 5, T(0));
   for (size_t i = 0; i < cull_rec.size(); i++)
-    for (int comp = 0; comp < 5; comp++) H.ocull8[(i / 8) * 40 + comp * 8 + (i % 8)] = T(cull_rec[i][comp]);
+    for (int comp = 0; comp < 5; comp++) H.ocullq[(i / 4) * 20 + comp * 4 + (i % 4)] = T(cull_rec[i][comp]);
   // self pairs -> shape ranges; a pair whose joint has no model never yields
   // (collision_checker.rs:150-159)
   for (int p = 0; p < r.n_pairs; p++) {

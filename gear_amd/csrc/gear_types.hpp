@@ -77,12 +77,12 @@ struct SceneDev {
   const ShapeDev<T>* rshapes;
   const ShapeDev<T>* oshapes;
   const T* ocull;  // [n_obs][4]: world bounding sphere cx,cy,cz and radius + margin (pre-inflated)
-  // cull records for the batched kernel in blocks of 8 obstacles, component-major inside a block:
-  // [n_obs_pad / 8][5][8] = -2cx, -2cy, -2cz, -2R, k  with R = obstacle radius + margin (inflated) and
+  // cull records for the batched kernels in quads of 4 obstacles, component-major inside a quad:
+  // [n_obs_pad / 4][5][4] = -2cx, -2cy, -2cz, -2R, k  with R = obstacle radius + margin (inflated) and
   // k = |c|^2 - R^2 - tau; n_obs_pad is a multiple of 32 (tail = far dummies).  Then
   //   d^2 - (rho + R)^2 = (|p|^2 - rho^2) + k + p . (-2c) + rho * (-2R)      (five VALU ops per pair)
-  // and a block is 40 consecutive dwords: wide scalar loads, one block ahead of the arithmetic.
-  const T* ocull8;
+  // and a quad is 20 consecutive dwords: wide scalar loads, one quad ahead of the arithmetic.
+  const T* ocullq;
   int32_t n_obs_pad, pad2;
   const PairDev* pairs;
   const int32_t* spairs;  // [n_spairs][4]: s1, s2, node-pair index, 0

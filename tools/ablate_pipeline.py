@@ -1,6 +1,6 @@
 """Pipeline vs fused: flags must be identical; per-path timings (profiling helper, not a test)."""
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from gear_amd import engine, workloads as W
 import bench
 FUSED, PIPE = 0x1000, 0x2000
