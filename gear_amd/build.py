@@ -26,5 +26,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "libgear_host.so")
+HOST_SOURCES = [os.path.join(_HERE, "host", f) for f in ("gear_host_capi.cpp", "gear_host.hpp")]
+HOST_HEADER = os.path.join(_HERE, "..", "include", "gear_host.h")
+
+
+def host_is_stale() -> bool:
+    if not os.path.exists(HOST_LIB_PATH):
+        return True
+    t = os.path.getmtime(HOST_LIB_PATH)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in HOST_SOURCES + [HOST_HEADER, HEADER])
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The C++ host layer (planner, RRT driver, URDF flattening) -> gear_amd/libgear_host.so, linked
+    against libgear_hip.so next to it.  Plain g++: no device code in it."""
+    build(False, verbose)
+    if force or host_is_stale():
+        cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra", "-o", HOST_LIB_PATH, HOST_SOURCES[0],
+               "-L" + _HERE, "-lgear_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -88,7 +88,7 @@ class JointPathPlanner:
         """k::Chain::set_joint_positions incl. the partially-set state it leaves behind on Err."""
         nodes = self.collision_check_robot.nodes
         if len(q) != len(using):
-            raise DofMismatch(len(q), len(using))
+            return False          # Err(DofMismatch) folds to `false` like any other Err (:79-82)
         for i, v in zip(using, q):
             n = nodes[i]
             if n.mimic_parent >= 0:
@@ -160,9 +160,9 @@ class JointPathPlanner:
         current = [self.positions[i] for i in using_joints]
         for part, q in (("Start", start), ("End", goal)):
             if not self.is_feasible(using_joints, q, objects):
-                names = self.colliding_link_names(objects)
+                # the reference restores the joints (:156) before it collects the names (:159)
                 self._set_joint_positions(using_joints, current)
-                raise Collision(part, names)
+                raise Collision(part, self.colliding_link_names(objects))
 
     def joint_names(self) -> List[str]:
         return self.collision_check_robot.joint_names()

@@ -314,3 +314,35 @@ def robot_from_dict(d: dict, base_dir: Optional[str] = None) -> UrdfRobot:
                             tuple(j["axis"]), j["lower"], j["upper"], j["mimic_joint"],
                             j["mimic_multiplier"], j["mimic_offset"]))
     return UrdfRobot(d["name"], links, joints, base_dir)
+
+
+def robot_to_xml(robot: UrdfRobot) -> str:
+    """Serialise a parsed robot back to URDF text (17 significant digits), e.g. to hand a JSON
+    fixture to the C++ host layer, which reads URDF files."""
+    def f(v):
+        return " ".join(repr(float(x)) for x in v)
+    out = [f'<?xml version="1.0"?>', f'<robot name="{robot.name}">']
+    for l in robot.links:
+        out.append(f'  <link name="{l.name}">')
+        for c in l.collisions:
+            g = c.geometry
+            if g.kind == "box":
+                ge = f'<box size="{f(g.size)}"/>'
+            elif g.kind == "cylinder":
+                ge = f'<cylinder radius="{float(g.radius)!r}" length="{float(g.length)!r}"/>'
+            elif g.kind == "sphere":
+                ge = f'<sphere radius="{float(g.radius)!r}"/>'
+            else:
+                ge = f'<mesh filename="{g.filename}" scale="{f(g.scale)}"/>'
+            out.append(f'    <collision><origin xyz="{f(c.xyz)}" rpy="{f(c.rpy)}"/><geometry>{ge}</geometry></collision>')
+        out.append('  </link>')
+    for j in robot.joints:
+        out.append(f'  <joint name="{j.name}" type="{j.type}">')
+        out.append(f'    <origin xyz="{f(j.xyz)}" rpy="{f(j.rpy)}"/><parent link="{j.parent}"/><child link="{j.child}"/>')
+        out.append(f'    <axis xyz="{f(j.axis)}"/><limit lower="{float(j.lower)!r}" upper="{float(j.upper)!r}"/>')
+        if j.mimic_joint:
+            out.append(f'    <mimic joint="{j.mimic_joint}" multiplier="{float(j.mimic_multiplier)!r}" '
+                       f'offset="{float(j.mimic_offset)!r}"/>')
+        out.append('  </joint>')
+    out.append('</robot>')
+    return "\n".join(out) + "\n"

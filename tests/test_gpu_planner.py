@@ -60,12 +60,13 @@ def test_predicates_match_oracle_and_keep_state(sample_robot, obstacles_robot):
     # arm-only using_joints (examples/minimum.rs:35): the gripper keeps the state set above
     arm = planner.collision_check_robot.serial_chain_from_end(planner.collision_check_robot.find("l_tool_fixed"))
     assert len(arm) == 6
-    with pytest.raises(P.DofMismatch):
-        planner.is_feasible(arm, q[0], objects)
+    assert planner.is_feasible(arm, q[0], objects) is False   # Err(DofMismatch) folds to false (:79-82)
     assert isinstance(planner.is_feasible(arm, q[0][:6], objects), bool)
     # start/goal validation raises gear::Error::Collision with the colliding link names
     colliding = q[np.nonzero((flags & 1) != 0)[0][0]]
     free = q[np.nonzero(flags == 0)[0][0]]
     with pytest.raises(P.Collision) as e:
         planner.check_start_goal(using, free, colliding, objects)
-    assert e.value.part == "End" and len(e.value.collision_link_names) > 0
+    # the reference restores the joints before collecting the names (:156-159): they describe the
+    # restored state, which is the free one here
+    assert e.value.part == "End" and e.value.collision_link_names == planner.colliding_link_names(objects)
