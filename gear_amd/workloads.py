@@ -185,15 +185,65 @@ def straight_edges(chain: U.Chain, using: Sequence[int], n_edges: int, seed: int
     return np.asarray(qs, dtype=dtype), np.asarray(off, np.uint32)
 
 
+def convex_mesh(rng, scale, n_min=8, n_max=24):
+    """A random closed convex triangle mesh (<= 64 vertices): the hull of points on a squashed sphere."""
+    from scipy.spatial import ConvexHull
+    pts = rng.normal(size=(int(rng.integers(n_min, n_max + 1)), 3))
+    pts *= np.asarray(scale) / np.linalg.norm(pts, axis=1, keepdims=True)
+    hull = ConvexHull(pts)
+    used = np.unique(hull.simplices)
+    remap = {int(o): i for i, o in enumerate(used)}
+    return pts[used].tolist(), [[remap[int(i)] for i in s] for s in hull.simplices]
+
+
+def dual_arm_robot() -> U.UrdfRobot:
+    """A PR2-like upper body: base, a prismatic torso lift, and two 7-DOF arms branching off the torso
+    (17 nodes with the root, 15 movable joints).  Link geometry here is boxes; `pr2_workload` replaces
+    most of it by convex meshes."""
+    links = [_link("base", [((0, 0, 0.15), (0, 0, 0), _box(0.6, 0.6, 0.3))]),
+             _link("torso", [((-0.05, 0, 0.35), (0, 0, 0), _box(0.3, 0.4, 0.7))])]
+    joints = [U.Joint("torso_lift", "prismatic", (0, 0, 0.3), (0, 0, 0), "base", "torso", (0, 0, 1), 0.0, 0.3)]
+    for side, sy in (("l", 1.0), ("r", -1.0)):
+        names = [f"{side}_{n}" for n in ("shoulder_pan", "shoulder_lift", "upper_arm", "elbow", "forearm", "wrist_flex",
+                                         "gripper")]
+        sizes = [(0.16, 0.16, 0.2), (0.14, 0.14, 0.14), (0.4, 0.12, 0.12), (0.12, 0.12, 0.12), (0.32, 0.1, 0.1),
+                 (0.1, 0.1, 0.1), (0.14, 0.12, 0.06)]
+        offs = [(0, 0, 0), (0, 0, 0), (0.2, 0, 0), (0, 0, 0), (0.16, 0, 0), (0, 0, 0), (0.08, 0, 0)]
+        for n, sz, of in zip(names, sizes, offs):
+            links.append(_link(n + "_link", [(of, (0, 0, 0), _box(*sz))]))
+        org = [(0.0, 0.19 * sy, 0.55), (0.1, 0, 0), (0, 0, 0), (0.4, 0, 0), (0, 0, 0), (0.32, 0, 0), (0, 0, 0)]
+        axes = [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 1, 0), (1, 0, 0), (0, 1, 0), (1, 0, 0)]
+        lim = [(-2.1 if sy < 0 else -0.7, 0.7 if sy < 0 else 2.1), (-0.5, 1.3), (-3.0, 3.0), (-2.3, 0.0), (-3.1, 3.1),
+               (-2.0, 0.0), (-3.1, 3.1)]
+        parent = "torso"
+        for n, o, a, (lo, hi) in zip(names, org, axes, lim):
+            joints.append(_rev(n, parent, n + "_link", o, a, lo, hi))
+            parent = n + "_link"
+    return U.UrdfRobot("dual_arm", links, joints)
+
+
+def dual_arm_self_pairs() -> List[Tuple[str, str]]:
+    """Every left-arm joint against every right-arm joint from the upper arm down, both forearms and
+    grippers against the torso and the base."""
+    tail = ("upper_arm", "elbow", "forearm", "wrist_flex", "gripper")
+    pairs = [(f"l_{a}", f"r_{b}") for a in tail for b in tail]
+    for side in ("l", "r"):
+        for n in ("forearm", "wrist_flex", "gripper"):
+            pairs += [(f"{side}_{n}", "torso_lift"), (f"{side}_{n}", "root")]
+    return pairs
+
+
 class Workload:
     """A flattened robot + obstacle scene plus what is needed to draw inputs for it."""
 
     def __init__(self, name: str, robot: U.UrdfRobot, objects: D.Compound, margin: float,
-                 self_pairs: Sequence[Tuple[str, str]] = (), end_joint: Optional[str] = None):
+                 self_pairs: Sequence[Tuple[str, str]] = (), end_joint: Optional[str] = None, model_edit=None):
         self.name = name
         self.robot = robot
         self.chain = U.Chain.from_urdf(robot)
         self.model = D.CollisionModel.from_urdf_robot(robot, margin)
+        if model_edit is not None:
+            model_edit(self.model)
         self.model.self_collision_pairs = list(self_pairs)
         self.objects = objects
         self.margin = margin
@@ -232,6 +282,26 @@ def sawyer_workload(n_obstacles: int = 4096, seed: int = 2, margin: float = 0.01
     return Workload("arm7_vs_%d_mixed" % n_obstacles, arm7_robot(),
                     obstacle_field(n_obstacles, seed, ("box", "ball", "cyl"), (0.4, 0.3, 0.3), cube=4.0), margin,
                     ARM7_SELF_PAIRS)
+
+
+def pr2_workload(n_obstacles: int = 128, seed: int = 4, margin: float = 0.01, end_joint: Optional[str] = None) -> Workload:
+    """configs[4]: a dual-arm robot whose arm links are convex meshes (<= 64 vertices; gear's
+    urdf.rs:54-71 would load them with assimp), with the full arm-vs-arm self pair list.  17 robot
+    shapes in a branching chain: exercises the multi-chunk sweep, the FK branch slots and the general
+    mesh support function."""
+    rng = np.random.Generator(np.random.Philox(seed + 1000))
+
+    def to_meshes(model: D.CollisionModel):
+        for name, specs in model.name_collision_model_map.items():
+            if name in ("root", "torso_lift") or name.endswith("elbow"):
+                continue                       # boxes stay boxes
+            for i, sp in enumerate(specs):
+                v, t = convex_mesh(rng, np.asarray(sp.params) * rng.uniform(0.9, 1.1, 3))
+                specs[i] = D.ShapeSpec.mesh(v, t, sp.t, sp.q)
+
+    field = obstacle_field(n_obstacles, seed, ("box", "ball"), (0.6, 0.4), cube=2.8, base=(0.0, 0.0, 0.5), keep_out=0.55)
+    return Workload("dual_arm_mesh_vs_%d" % n_obstacles, dual_arm_robot(), field, margin, dual_arm_self_pairs(),
+                    end_joint, model_edit=to_meshes)
 
 
 def sample_workload(sample_robot: U.UrdfRobot, obstacles_robot: U.UrdfRobot, margin: float = 0.01,
