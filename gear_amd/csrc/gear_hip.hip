@@ -122,6 +122,14 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
   sc->n_slots = S.n_slots;
   sc->max_shape_node = H.rshapes.empty() ? -1 : H.rshapes.back().node;
+  // survivors per configuration grow with the number of obstacles in reach: 16 per configuration for up
+  // to 256 obstacles, proportionally more for denser scenes (GEAR_HIP_ITEM_CAP overrides; a region that
+  // still overflows is re-checked by the fused kernel)
+  {
+    size_t cap = 1024 * std::max<size_t>(1, (H.oshapes.size() + 255) / 256);
+    if (const char* e = getenv("GEAR_HIP_ITEM_CAP")) cap = (size_t)strtoull(e, nullptr, 0);
+    sc->item_cap = (unsigned)std::min<size_t>(std::max<size_t>(cap, 64), kMaxItemCap);
+  }
   return GH_OK;
 }
 
@@ -224,7 +232,10 @@ void launch_sweep_k(const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what,
 template <class T>
 int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags,
                  hipStream_t st) {
-  const size_t chunk = std::min((n + kWave - 1) / kWave * kWave, pipe_chunk());
+  // a wave's queue region holds item_cap survivors; keep the whole queue near 1 GiB and the wave index
+  // inside the bits an exact entry leaves for it
+  const size_t max_waves = std::min<size_t>((size_t(1) << 30) / ((size_t)sc->item_cap * (4 + 7 * sizeof(T))), size_t(1) << (32 - kItemBits));
+  const size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, pipe_chunk(), std::max<size_t>(max_waves, 64) * kWave});
   const size_t waves = chunk / kWave;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
   PipeWs<T> W{};

@@ -28,7 +28,8 @@
 namespace gear_hip {
 
 constexpr int kExLds = 512;           // per-workgroup staging of exact entries in k_narrow1
-constexpr int kMaxItemCap = 1024;     // an exact entry packs the item index into 10 bits
+constexpr int kItemBits = 13;          // an exact entry packs (wave << kItemBits) | item index
+constexpr int kMaxItemCap = 1 << kItemBits;
 
 struct WaveHdr {
   unsigned count;     // items pushed by the wave (may exceed the capacity: then `overflow` is set)
@@ -49,7 +50,7 @@ template <class T> struct PipeWs {
   unsigned* codes;       // [waves][cap]
   T* qpose;              // [waves][7][cap]  world pose of an env item's robot shape
   unsigned* hit;         // [configs]
-  unsigned* exact;       // [cap2]  wave << 10 | item
+  unsigned* exact;       // [cap2]  wave << kItemBits | item
   PipeCounters* pc;
   T* pstore;             // [L][7][stride]  every shape pose (self pairs only)
   size_t stride;
@@ -372,7 +373,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
         __syncthreads();
         if (ebase + cnt > W.cap2) redo = true;
         else
-          for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[ebase + k] = ((unsigned)wave << 10) | exq[k];
+          for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[ebase + k] = ((unsigned)wave << kItemBits) | exq[k];
         __syncthreads();
         if (tid == 0) en = 0;
         __syncthreads();
@@ -404,8 +405,8 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
   LaneCounters lc{0, 0, 0, 0};
   for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads) {
     const unsigned ent = W.exact[e];
-    const size_t wave = ent >> 10;
-    const unsigned j = ent & 1023u;
+    const size_t wave = ent >> kItemBits;
+    const unsigned j = ent & (unsigned)(kMaxItemCap - 1);
     const unsigned code = W.codes[wave * W.cap + j];
     const size_t cfg = wave * kWave + (code & 63u);
     const unsigned bit = (code >> 31) ? 2u : 1u;
