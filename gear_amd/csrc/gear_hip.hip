@@ -119,6 +119,11 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   S.n_spairs = (int)H.spair_r.size();
   if ((rc = upload(sc, H.verts, &S.verts))) return rc;
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
+  if ((rc = upload(sc, H.grids, &S.grids))) return rc;
+  if ((rc = upload(sc, H.shape_grid, &S.shape_grid))) return rc;
+  if ((rc = upload(sc, H.cell_off, &S.cell_off))) return rc;
+  if ((rc = upload(sc, H.cell_items, &S.cell_items))) return rc;
+  S.n_grids = (int)H.grids.size();
   sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
   sc->n_slots = S.n_slots;
   sc->max_shape_node = H.rshapes.empty() ? -1 : H.rshapes.back().node;
@@ -221,6 +226,7 @@ size_t pipe_chunk() {  // GEAR_HIP_PIPE_CHUNK overrides (tuning aid)
 }
 constexpr size_t kPipeMin = size_t(1) << 14;    // smaller batches take the fused kernel alone
 constexpr uint32_t kForceFused = 0x1000u, kForcePipe = 0x2000u;  // `what` bits for tests and profiling
+constexpr uint32_t kNoGrid = 0x4000u;                             // pipeline without the broadphase grid
 
 template <class T, int K>
 void launch_sweep_k(const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, const PipeWs<T>& W, int lds_centres,
@@ -271,14 +277,20 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const size_t sc_bytes = (size_t)(max_node + 1) * 2 * kWave * sizeof(T);
   const size_t lds = slot_bytes + sc_bytes + (lds_centres ? cen_bytes : 0);
   const int K = pick_chunk(sc->L);
+  const bool use_grid = S.n_grids > 0 && (what & 1u) && !(what & kNoGrid);
   for (size_t off = 0; off < n; off += chunk) {
     const size_t cnt = std::min(chunk, n - off);
     const T* qc = q + off * sc->D;
     GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), st));
-    switch (K) {
-      case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
-      case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
-      default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+    if (use_grid) {
+      hipLaunchKernelGGL((k_sweep_grid<T>), dim3(grid_for(cnt)), dim3(kWave), lds - sc_bytes + 16, st, S, qc, cnt, what, W, lds_centres,
+                         max_node);
+    } else {
+      switch (K) {
+        case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+        case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+        default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+      }
     }
     hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kN1Threads), 0, st, S, cnt, what, W);
     const unsigned g2 = (unsigned)std::min<size_t>(2048, (cnt + 255) / 256);
@@ -439,6 +451,22 @@ int gh_check_batch_counted(gh_scene* sc, const void* q_dev, size_t n, uint32_t w
   std::memset(out, 0, sizeof(*out));
   out->configs = h.configs; out->pairs = h.pairs; out->cull_pass = h.cull_pass;
   out->sat_tests = h.sat_tests; out->exact_tests = h.exact_tests; out->exact_iters = h.exact_iters;
+  return GH_OK;
+}
+
+int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
+  if (!sc || !out) return fail(GH_ERR_INVALID, "null argument");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!sc->p_pc.p) return GH_OK;
+  GH_HIP(hipDeviceSynchronize());
+  PipeCounters h;
+  GH_HIP(hipMemcpy(&h, sc->p_pc.p, sizeof(h), hipMemcpyDeviceToHost));
+  out[0] = h.candidates;
+  out[1] = h.exact;
+  out[2] = h.overflow;
+  out[3] = sc->item_cap;
   return GH_OK;
 }
 

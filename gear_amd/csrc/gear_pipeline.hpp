@@ -41,7 +41,7 @@ struct WaveHdr {
 struct PipeCounters {
   unsigned exact;     // entries in the exact queue
   unsigned overflow;  // the exact queue ran full
-  unsigned pad[2];
+  unsigned long long candidates;  // broadphase candidates tested (only with GH_COUNT_CANDIDATES in `what`)
 };
 
 // layout of one launch chunk's workspace
@@ -273,6 +273,155 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
           b[3 * W.stride] = P[j].r.i; b[4 * W.stride] = P[j].r.j; b[5 * W.stride] = P[j].r.k; b[6 * W.stride] = P[j].r.w;
         }
       }
+    }
+  }
+
+  const unsigned long long bad = __ballot(live && !ok);
+  if (lane == 0) W.hdr[wave] = {count, (unsigned)bad, (unsigned)(bad >> 32), overflow ? 1u : 0u};
+}
+
+// ---------------------------------------------------------------------------
+// k_sweep_grid: the sweep with a broadphase.  Instead of testing a robot shape against every
+// obstacle, the lane looks up the grid cell its shape centre falls in (one grid per class of shape
+// radius, built on the host: gear_scene.hpp build_grids) and tests only the obstacles listed there.
+// Shapes are handled one at a time as the FK walk produces them, so no pose has to stay in
+// registers; survivors take their queue slot from an LDS counter.  With self pairs every shape pose
+// goes to the pose store.  Same queue format as k_sweep; the flags are identical because every pair
+// whose bounding spheres overlap is listed (conservative lists), and pairs that do not cannot collide.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kWave)
+k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres, int max_node) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
+  const Views<T> V(S);
+  const int lane = threadIdx.x;
+  const size_t wave = blockIdx.x;
+  const size_t col = wave * kWave + lane;
+  const bool live = col < n;
+  const size_t i = live ? col : n - 1;
+  const T* qrow = q + i * (size_t)S.n_cols;
+  unsigned* cnt = reinterpret_cast<unsigned*>(gear_lds);  // queue fill of this wave
+  const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds + 16), (size_t)kWave, (size_t)lane};
+  T* cen = reinterpret_cast<T*>(gear_lds + 16 + (size_t)S.n_slots * 7 * kWave * sizeof(T));  // [L][3][64]
+  (void)max_node;  // this kernel is light on registers: half-angle sin/cos are computed inside the walk
+  if (lane == 0) *cnt = 0u;
+
+  const bool ok = limits_ok(S, V, qrow);
+  const bool do_env = (what & 1u) && S.n_obs > 0;
+  const bool do_self = (what & 2u) && S.n_spairs > 0;
+  const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
+  const bool dbg_no_sweep = (what & 0x800u) != 0;
+
+  unsigned* codes = W.codes + wave * W.cap;
+  T* qpose = W.qpose + wave * 7 * (size_t)W.cap;
+  const GEAR_CAS GridDev<T>* grids = to_cas(S.grids);
+  const GEAR_CAS int32_t* shape_grid = to_cas(S.shape_grid);
+  const uint32_t* __restrict__ cell_off = S.cell_off;
+  const uint16_t* __restrict__ cell_items = S.cell_items;
+  const T* __restrict__ ocull = S.ocull;
+
+  const int n_walk = (do_env || do_self) ? S.n_shapes : 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  int node = -1;
+  Pose<T> cur{{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
+  for (int s = 0; s < n_walk; s++) {
+    const GEAR_CAS ShapeDev<T>* sh = V.rshapes + s;
+    const int target = sh->node;
+    while (node < target) {
+      node++;
+      node_world(V, node, qrow, slots, cur);
+    }
+    const Pose<T> ws = pose_mul(cur, shape_pose<T>(sh));
+    if (do_self) {
+      if (live) {
+        T* b = W.pstore + (size_t)s * 7 * W.stride + col;
+        b[0] = ws.t.x; b[W.stride] = ws.t.y; b[2 * W.stride] = ws.t.z;
+        b[3 * W.stride] = ws.r.i; b[4 * W.stride] = ws.r.j; b[5 * W.stride] = ws.r.k; b[6 * W.stride] = ws.r.w;
+      }
+      if (lds_centres) {
+        T* cc = cen + (size_t)s * 3 * kWave + lane;
+        cc[0] = ws.t.x; cc[kWave] = ws.t.y; cc[2 * kWave] = ws.t.z;
+      }
+    }
+    if (!do_env || dbg_no_sweep) continue;
+    // ---- cell lookup ---------------------------------------------------------------------------
+    const GEAR_CAS GridDev<T>* g = grids + shape_grid[s];
+    const T fx = (ws.t.x - g->org[0]) * g->inv_h, fy = (ws.t.y - g->org[1]) * g->inv_h, fz = (ws.t.z - g->org[2]) * g->inv_h;
+    const bool inside = push_ok && fx >= T(0) && fy >= T(0) && fz >= T(0) && fx < T(g->nx) && fy < T(g->ny) && fz < T(g->nz);
+    unsigned k = 0, e = 0;
+    if (inside) {
+      const unsigned cell = (unsigned)g->off_base + ((unsigned)(int)fz * (unsigned)g->ny + (unsigned)(int)fy) * (unsigned)g->nx + (unsigned)(int)fx;
+      k = cell_off[cell];
+      e = cell_off[cell + 1];
+    }
+    const T rho = sh->br;
+    if (what & 0x8000u) atomicAdd(&W.pc->candidates, (unsigned long long)(e - k));  // diagnostic count
+    auto test_push = [&](bool valid, unsigned o, T ox, T oy, T oz, T orad) {
+      const T dx = ws.t.x - ox, dy = ws.t.y - oy, dz = ws.t.z - oz;
+      const T rr = rho + orad;
+      if (valid && dx * dx + dy * dy + dz * dz < rr * rr) {
+        const unsigned pos = atomicAdd(cnt, 1u);
+        if (pos < W.cap) {
+          codes[pos] = (o << 16) | ((unsigned)s << 6) | (unsigned)lane;
+          T* b = qpose + pos;
+          b[0] = ws.t.x; b[W.cap] = ws.t.y; b[2 * W.cap] = ws.t.z;
+          b[3 * W.cap] = ws.r.i; b[4 * W.cap] = ws.r.j; b[5 * W.cap] = ws.r.k; b[6 * W.cap] = ws.r.w;
+        }
+      }
+    };
+    while (__ballot(k < e) != 0) {
+      const bool v0 = k < e;
+      const unsigned o0 = v0 ? cell_items[k] : 0u;
+      test_push(v0, o0, ocull[4 * o0], ocull[4 * o0 + 1], ocull[4 * o0 + 2], ocull[4 * o0 + 3]);
+      k++;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  unsigned count = *cnt;  // wave-uniform
+  bool overflow = count > W.cap;
+
+  // ---- self shape pairs (as in k_sweep, poses already in the pose store) --------------------------
+  if (do_self) {
+    if (!lds_centres) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int p0 = 0; p0 < S.n_spairs; p0 += 32) {
+      const int pc = min(32, S.n_spairs - p0);
+      unsigned m = 0;
+      for (int kk = 0; kk < pc; kk++) {
+        const int s1 = V.spairs[4 * (p0 + kk)], s2 = V.spairs[4 * (p0 + kk) + 1];
+        V3<T> c1, c2;
+        if (lds_centres) {
+          const T* a = cen + (size_t)s1 * 3 * kWave + lane;
+          const T* b = cen + (size_t)s2 * 3 * kWave + lane;
+          c1 = {a[0], a[kWave], a[2 * kWave]};
+          c2 = {b[0], b[kWave], b[2 * kWave]};
+        } else {
+          const T* a = W.pstore + (size_t)s1 * 7 * W.stride + (live ? col : 0);
+          const T* b = W.pstore + (size_t)s2 * 7 * W.stride + (live ? col : 0);
+          c1 = {a[0], a[W.stride], a[2 * W.stride]};
+          c2 = {b[0], b[W.stride], b[2 * W.stride]};
+        }
+        const V3<T> d = c1 - c2;
+        const T rr = V.spair_r[p0 + kk];
+        m |= (push_ok && dot(d, d) < rr * rr) ? (0x80000000u >> kk) : 0u;
+      }
+      const unsigned nl = (unsigned)__popc(m);
+      if (__ballot(nl != 0) == 0) continue;
+      unsigned off, tot;
+      wave_offsets(nl, off, tot);
+      if (count + tot > W.cap) {
+        overflow = true;
+      } else {
+        unsigned pos = count + off;
+        while (m != 0) {
+          const int z = __clz(m);
+          m &= ~(0x80000000u >> z);
+          codes[pos++] = 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane;
+        }
+      }
+      count += tot;
     }
   }
 

@@ -31,6 +31,10 @@ struct HostTables {
   std::vector<int32_t> spairs;  // flattened self shape pairs: [n][4] = s1, s2, node-pair index, 0
   std::vector<T> spair_r;       // [n] bounding radii sum + margin, inflated
   std::vector<T> verts, planes;
+  std::vector<GridDev<T>> grids;
+  std::vector<int32_t> shape_grid;
+  std::vector<uint32_t> cell_off;
+  std::vector<uint16_t> cell_items;
   int n_slots = 0;
   T margin = 0;
 };
@@ -212,6 +216,89 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
   return true;
 }
 
+// Broadphase grids, one per class of robot-shape bounding radius (at most 4 classes, split at the
+// radius quantiles; a class uses its largest radius).  Conservative by construction: obstacle o is
+// listed in every cell whose box is within R_o + margin + rho_class + slack of its centre, all in f64;
+// the slack covers the f32 rounding of the cell lookup on the device.
+template <class T>
+inline void build_grids(HostTables<T>& H, double margin) {
+  const size_t O = H.oshapes.size(), L = H.rshapes.size();
+  H.shape_grid.assign(L, 0);
+  if (O < 32 || L == 0) return;  // small fields are swept directly
+  std::vector<double> radii;
+  for (auto& s : H.rshapes) radii.push_back((double)s.br);
+  std::vector<double> sorted = radii;
+  std::sort(sorted.begin(), sorted.end());
+  sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+  const int n_cls = (int)std::min<size_t>(4, sorted.size());
+  std::vector<double> cls_r(n_cls);
+  for (int c = 0; c < n_cls; c++) cls_r[c] = sorted[(size_t)((c + 1) * sorted.size() / n_cls) - 1];
+  for (size_t s = 0; s < L; s++) {
+    int c = 0;
+    while (radii[s] > cls_r[c]) c++;
+    H.shape_grid[s] = c;
+  }
+  for (int c = 0; c < n_cls; c++) {
+    std::vector<double> reach(O);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t o = 0; o < O; o++) {
+      const double R = (double)H.ocull[4 * o + 3];  // bounding radius + margin, already inflated
+      reach[o] = (R + cls_r[c]) * (1.0 + 1e-5);
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(lo[k], (double)H.ocull[4 * o + k] - reach[o]);
+        hi[k] = std::max(hi[k], (double)H.ocull[4 * o + k] + reach[o]);
+      }
+    }
+    (void)margin;
+    const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
+    const double slack = 1e-5 + 2e-6 * (ext + std::fabs(lo[0]) + std::fabs(lo[1]) + std::fabs(lo[2]));
+    std::vector<double> sr(reach);
+    std::sort(sr.begin(), sr.end());
+    const double h = std::max({ext / 48.0, 0.5 * sr[O / 2], 0.02});
+    GridDev<T> g;
+    int n[3];
+    for (int k = 0; k < 3; k++) {
+      lo[k] -= slack;
+      n[k] = std::max(1, (int)std::ceil((hi[k] + slack - lo[k]) / h));
+      g.org[k] = T(lo[k]);
+    }
+    g.inv_h = T(1.0 / h);
+    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    g.off_base = (int32_t)H.cell_off.size();
+    const size_t ncell = (size_t)n[0] * n[1] * n[2];
+    // the device computes floor((p - org) * inv_h) with ITS org and inv_h: use the same rounded values
+    const double orgd[3] = {(double)g.org[0], (double)g.org[1], (double)g.org[2]}, hd = 1.0 / (double)g.inv_h;
+    std::vector<std::vector<uint16_t>> cells(ncell);
+    for (size_t o = 0; o < O; o++) {
+      const double cx[3] = {(double)H.ocull[4 * o], (double)H.ocull[4 * o + 1], (double)H.ocull[4 * o + 2]};
+      const double r = reach[o] + slack;
+      int a[3], b[3];
+      for (int k = 0; k < 3; k++) {
+        a[k] = std::max(0, (int)std::floor((cx[k] - r - orgd[k]) / hd) - 1);
+        b[k] = std::min(n[k] - 1, (int)std::floor((cx[k] + r - orgd[k]) / hd) + 1);
+      }
+      for (int iz = a[2]; iz <= b[2]; iz++)
+        for (int iy = a[1]; iy <= b[1]; iy++)
+          for (int ix = a[0]; ix <= b[0]; ix++) {
+            const int ic[3] = {ix, iy, iz};
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) {
+              const double bl = orgd[k] + ic[k] * hd, bh = bl + hd;
+              const double d = cx[k] < bl ? bl - cx[k] : cx[k] > bh ? cx[k] - bh : 0.0;
+              d2 += d * d;
+            }
+            if (d2 <= r * r) cells[((size_t)iz * n[1] + iy) * n[0] + ix].push_back((uint16_t)o);
+          }
+    }
+    for (size_t i = 0; i < ncell; i++) {
+      H.cell_off.push_back((uint32_t)H.cell_items.size());
+      H.cell_items.insert(H.cell_items.end(), cells[i].begin(), cells[i].end());
+    }
+    H.cell_off.push_back((uint32_t)H.cell_items.size());
+    H.grids.push_back(g);
+  }
+}
+
 }  // namespace detail
 
 template <class T>
@@ -331,6 +418,7 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
   H.ocullq.assign(cull_rec.size() * 5, T(0));
   for (size_t i = 0; i < cull_rec.size(); i++)
     for (int comp = 0; comp < 5; comp++) H.ocullq[(i / 4) * 20 + comp * 4 + (i % 4)] = T(cull_rec[i][comp]);
+  detail::build_grids<T>(H, std::max(margin, 0.0));
   // self pairs -> shape ranges; a pair whose joint has no model never yields
   // (collision_checker.rs:150-159)
   for (int p = 0; p < r.n_pairs; p++) {

@@ -61,6 +61,18 @@ struct PairDev {
   int32_t s2_begin, s2_end;  // shapes of joint 2
 };
 
+// One uniform grid over the obstacle field for a class of robot-shape radii (broadphase of the
+// large-batch sweep).  Cell (ix,iy,iz) lists every obstacle whose bounding sphere, inflated by the
+// margin and by the class radius, reaches the cell's box: a robot shape of that class whose centre
+// falls in the cell can only be within reach of listed obstacles.
+template <class T>
+struct GridDev {
+  T org[3];        // world position of the grid's low corner
+  T inv_h;         // 1 / cell size
+  int32_t nx, ny, nz;
+  int32_t off_base;  // first entry of this grid in cell_off[] (nx*ny*nz + 1 entries)
+};
+
 struct CountersDev {
   unsigned long long configs, pairs, cull_pass, sat_tests, exact_tests, exact_iters, r0, r1;
 };
@@ -90,6 +102,12 @@ struct SceneDev {
   int32_t n_spairs, pad3;
   const T* verts;   // [..][3]
   const T* planes;  // [..][4]
+  // broadphase grids (n_grids == 0: none built)
+  const GridDev<T>* grids;      // [n_grids]
+  const int32_t* shape_grid;    // [n_shapes] grid of each robot shape
+  const uint32_t* cell_off;     // CSR offsets into cell_items, all grids concatenated
+  const uint16_t* cell_items;   // obstacle indices
+  int32_t n_grids, pad4;
 };
 
 }  // namespace gear_hip

@@ -20,7 +20,7 @@ SYMBOLS = [
     "gh_scene_create", "gh_scene_destroy", "gh_scene_dof", "gh_scene_nodes", "gh_scene_precision",
     "gh_scene_device", "gh_check_batch", "gh_check_batch_dev", "gh_check_edges", "gh_check_edges_dev",
     "gh_fk_batch", "gh_fk_batch_dev", "gh_link_hits", "gh_link_mask_words", "gh_self_hits",
-    "gh_check_batch_counted", "gh_last_error", "gh_version",
+    "gh_check_batch_counted", "gh_pipeline_last_stats", "gh_last_error", "gh_version",
 ]
 
 
@@ -51,6 +51,7 @@ def lib():
         L.gh_link_hits.argtypes = [vp, vp, sz, vp]
         L.gh_self_hits.argtypes = [vp, vp, sz, vp]
         L.gh_check_batch_counted.argtypes = [vp, vp, sz, u32, vp, vp]
+        L.gh_pipeline_last_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.gh_last_error.restype = C.c_char_p
         L.gh_version.restype = C.c_char_p
         _LIB = L
@@ -153,6 +154,11 @@ class Scene:
 
     def fk_batch_dev(self, q_t, poses_t, stream: Optional[int] = None):
         _check(lib().gh_fk_batch_dev(self.h, q_t.data_ptr(), q_t.shape[0], poses_t.data_ptr(), stream))
+
+    def pipeline_last_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        _check(lib().gh_pipeline_last_stats(self.h, out))
+        return {"candidates": int(out[0]), "exact_items": int(out[1]), "exact_overflow": int(out[2]), "item_cap": int(out[3])}
 
     def check_batch_counted(self, q_t, flags_t, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF) -> dict:
         c = D.gh_counters()

@@ -70,7 +70,9 @@ enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2 };
  * bytes are identical either way (tests/test_gpu_pipeline.py).  Without them
  * batches of >= 16384 configurations take the multi-kernel pipeline and
  * smaller ones the single fused kernel.  No counterpart in the reference. */
-enum { GH_PATH_FUSED = 0x1000, GH_PATH_PIPELINE = 0x2000 };
+enum { GH_PATH_FUSED = 0x1000, GH_PATH_PIPELINE = 0x2000,
+       GH_PATH_NO_GRID = 0x4000, /* pipeline: sweep every obstacle instead of the broadphase grid's cell lists */
+       GH_COUNT_CANDIDATES = 0x8000 /* count the broadphase candidates (gh_pipeline_last_stats) */ };
 
 /* ---- descriptors ------------------------------------------------------- */
 
@@ -207,6 +209,12 @@ int gh_self_hits(gh_scene* scene, const void* q, size_t n, uint64_t* pair_mask);
 /* Instrumented run (pairs culled / SAT'd / exact-tested; SURVEY.md 8d's s,g). */
 int gh_check_batch_counted(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
                            uint8_t* flags_dev, gh_counters* out);
+
+/* Diagnostic, no counterpart in the reference: counters of the LAST chunk of the last large-batch call
+ * on this scene (synchronises the device).  out[0] broadphase candidates tested (only when `what`
+ * carried GH_COUNT_CANDIDATES), out[1] items that needed the exact stage, out[2] != 0 when the exact
+ * queue overflowed (those configurations were re-checked), out[3] survivor-queue capacity per wave. */
+int gh_pipeline_last_stats(gh_scene* scene, uint64_t out[4]);
 
 const char* gh_last_error(void);
 const char* gh_version(void);

@@ -30,8 +30,10 @@ def test_pipeline_equals_fused(sample_robot, obstacles_robot, prec):
         q = w.configs(n, seed=21, dtype=hip.dtype, overshoot=0.02)
         for what in (BOTH, D.GH_CHECK_ENV, D.GH_CHECK_SELF):
             a = hip.check_batch(q, what | D.GH_PATH_FUSED)
-            b = hip.check_batch(q, what | D.GH_PATH_PIPELINE)
+            b = hip.check_batch(q, what | D.GH_PATH_PIPELINE)                       # broadphase grid
+            c = hip.check_batch(q, what | D.GH_PATH_PIPELINE | D.GH_PATH_NO_GRID)  # every obstacle swept
             assert (a == b).all(), (w.name, prec, what, int((a != b).sum()))
+            assert (a == c).all(), (w.name, prec, what, int((a != c).sum()))
         assert ((a | b) != 0).any()
         # ragged sizes around the wavefront width, through the pipeline
         for m in (1, 63, 64, 65, 129):
@@ -61,4 +63,5 @@ def test_pipeline_queue_overflow_is_rechecked():
     q = w.configs(4096, seed=23)
     a = hip.check_batch(q, BOTH | D.GH_PATH_FUSED)
     b = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE)
-    assert (a == b).all()
+    c = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE | D.GH_PATH_NO_GRID)
+    assert (a == b).all() and (a == c).all()
