@@ -62,6 +62,8 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int kMaxSets = 4;
+
 struct gh_scene {
   int precision = 32, device = 0;
   int D = 0, N = 0, L = 0, O = 0, P = 0, n_slots = 0;
@@ -73,7 +75,12 @@ struct gh_scene {
   hipStream_t stream = nullptr;
   std::mutex mu;
   DevBuf q, flags, out, edges, store, first;
-  DevBuf p_hdr, p_codes, p_qpose, p_hit, p_exact, p_pc, p_pstore;  // pipeline workspace (gear_pipeline.hpp)
+  // pipeline workspace (gear_pipeline.hpp): several sets, so that consecutive chunks of one call can be
+  // in flight together (set 0 on the caller's stream, set k on aux[k])
+  struct PipeBufs { DevBuf hdr, items, hit, exact, pc, pstore; } pw[kMaxSets];
+  hipStream_t aux[kMaxSets] = {};  // aux[0] unused: set 0 runs on the caller's stream
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSets] = {};
+  int last_sets = 0;  // workspace sets the last pipeline call used
   unsigned item_cap = 1024;  // survivor items per sweep wave before the fused path takes the wave over
   CountersDev* counters = nullptr;
   size_t elem() const { return precision == 32 ? 4 : 8; }
@@ -121,8 +128,7 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
   if ((rc = upload(sc, H.grids, &S.grids))) return rc;
   if ((rc = upload(sc, H.shape_grid, &S.shape_grid))) return rc;
-  if ((rc = upload(sc, H.cell_off, &S.cell_off))) return rc;
-  if ((rc = upload(sc, H.cell_items, &S.cell_items))) return rc;
+  if ((rc = upload(sc, H.cell_blk, &S.cell_blk))) return rc;
   S.n_grids = (int)H.grids.size();
   sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
   sc->n_slots = S.n_slots;
@@ -235,34 +241,56 @@ void launch_sweep_k(const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what,
                      max_node);
 }
 
+// GEAR_HIP_PIPE_STREAMS=1 keeps every chunk on the caller's stream (tuning aid; 1..kMaxSets)
+int pipe_streams() {
+  static const int v = [] {
+    const char* e = getenv("GEAR_HIP_PIPE_STREAMS");
+    const int x = e ? atoi(e) : kMaxSets;
+    return x < 1 ? 1 : x > kMaxSets ? kMaxSets : x;
+  }();
+  return v;
+}
+
 template <class T>
 int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags,
                  hipStream_t st) {
   // a wave's queue region holds item_cap survivors; keep the whole queue near 1 GiB and the wave index
   // inside the bits an exact entry leaves for it
-  const size_t max_waves = std::min<size_t>((size_t(1) << 30) / ((size_t)sc->item_cap * (4 + 7 * sizeof(T))), size_t(1) << (32 - kItemBits));
-  const size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, pipe_chunk(), std::max<size_t>(max_waves, 64) * kWave});
-  const size_t waves = chunk / kWave;
-  const bool do_self = (what & 2u) && S.n_spairs > 0;
-  PipeWs<T> W{};
-  W.cap = sc->item_cap;
-  W.cap2 = (unsigned)std::min<size_t>(chunk * 2, 0x7fffffffu);
-  W.stride = chunk;
-  int rc;
-  if ((rc = sc->p_hdr.ensure(waves * sizeof(WaveHdr))) || (rc = sc->p_codes.ensure(waves * W.cap * 4)) ||
-      (rc = sc->p_qpose.ensure(waves * W.cap * 7 * sizeof(T))) || (rc = sc->p_hit.ensure(chunk * 4)) ||
-      (rc = sc->p_exact.ensure((size_t)W.cap2 * 4)) || (rc = sc->p_pc.ensure(sizeof(PipeCounters))) ||
-      (do_self && (rc = sc->p_pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
-    return rc;
-  W.hdr = (WaveHdr*)sc->p_hdr.p;
-  W.codes = (unsigned*)sc->p_codes.p;
-  W.qpose = (T*)sc->p_qpose.p;
-  W.hit = (unsigned*)sc->p_hit.p;
-  W.exact = (unsigned*)sc->p_exact.p;
-  W.pc = (PipeCounters*)sc->p_pc.p;
-  W.pstore = (T*)sc->p_pstore.p;
+  const size_t max_waves = std::min<size_t>((size_t(1) << 30) / ((size_t)sc->item_cap * 8 * sizeof(T)), size_t(1) << (32 - kItemBits));
+  size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, pipe_chunk(), std::max<size_t>(max_waves, 64) * kWave});
   // the fused kernel is the last stage (flag conversion + re-checks): it needs its own pose columns
   StorePlan plan = plan_store(sc, true);
+  // Consecutive chunks are independent.  With several workspace sets they rotate over the caller's
+  // stream and the aux streams (fork / join through events), so that one chunk's narrow phase, which
+  // cannot fill the chip, overlaps the next chunk's sweep.  A batch that fits one chunk is split for that.
+  int n_sets = (!plan.global && n >= 4 * kPipeMin) ? pipe_streams() : 1;
+  if (n_sets > 1 && chunk * n_sets > n) chunk = ((n + n_sets - 1) / n_sets + kWave - 1) / kWave * kWave;
+  n_sets = (int)std::min<size_t>(n_sets, (n + chunk - 1) / chunk);
+  const bool two = n_sets > 1;
+  const size_t waves = chunk / kWave;
+  const bool do_self = (what & 2u) && S.n_spairs > 0;
+  PipeWs<T> Ws[kMaxSets];
+  int rc;
+  for (int k = 0; k < n_sets; k++) {
+    PipeWs<T>& W = Ws[k];
+    gh_scene::PipeBufs& b = sc->pw[k];
+    W = PipeWs<T>{};
+    W.cap = sc->item_cap;
+    W.cap2 = (unsigned)std::min<size_t>(chunk * 2, 0x7fffffffu);
+    W.stride = chunk;
+    if ((rc = b.hdr.ensure(waves * sizeof(WaveHdr))) || (rc = b.items.ensure(waves * W.cap * 8 * sizeof(T))) ||
+        (rc = b.hit.ensure(chunk * 4)) ||
+        (rc = b.exact.ensure((size_t)W.cap2 * 4)) || (rc = b.pc.ensure(sizeof(PipeCounters))) ||
+        (do_self && (rc = b.pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
+      return rc;
+    W.hdr = (WaveHdr*)b.hdr.p;
+    W.items = (T*)b.items.p;
+    W.hit = (unsigned*)b.hit.p;
+    W.exact = (unsigned*)b.exact.p;
+    W.pc = (PipeCounters*)b.pc.p;
+    W.pstore = (T*)b.pstore.p;
+  }
+  sc->last_sets = n_sets;
   void* gs = nullptr;
   size_t gstride = 0;
   if (plan.global) {
@@ -278,25 +306,40 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const size_t lds = slot_bytes + sc_bytes + (lds_centres ? cen_bytes : 0);
   const int K = pick_chunk(sc->L);
   const bool use_grid = S.n_grids > 0 && (what & 1u) && !(what & kNoGrid);
-  for (size_t off = 0; off < n; off += chunk) {
+  if (two) {
+    GH_HIP(hipEventRecord(sc->ev_fork, st));
+    for (int k = 1; k < n_sets; k++) GH_HIP(hipStreamWaitEvent(sc->aux[k], sc->ev_fork, 0));
+  }
+  size_t ci = 0;
+  for (size_t off = 0; off < n; off += chunk, ci++) {
     const size_t cnt = std::min(chunk, n - off);
     const T* qc = q + off * sc->D;
-    GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), st));
+    const int set = (int)(ci % (size_t)n_sets);
+    const PipeWs<T>& W = Ws[set];
+    hipStream_t cs = set ? sc->aux[set] : st;
+    GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
     if (use_grid) {
-      hipLaunchKernelGGL((k_sweep_grid<T>), dim3(grid_for(cnt)), dim3(kWave), lds - sc_bytes + 16, st, S, qc, cnt, what, W, lds_centres,
+      static const size_t lds_pad = [] { const char* e = getenv("GEAR_HIP_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
+      hipLaunchKernelGGL((k_sweep_grid<T>), dim3(grid_for(cnt)), dim3(kWave), lds - sc_bytes + lds_pad, cs, S, qc, cnt, what, W, lds_centres,
                          max_node);
     } else {
       switch (K) {
-        case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
-        case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
-        default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, st); break;
+        case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
+        case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
+        default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
       }
     }
-    hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kN1Threads), 0, st, S, cnt, what, W);
+    hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kN1Threads), 0, cs, S, cnt, what, W);
     const unsigned g2 = (unsigned)std::min<size_t>(2048, (cnt + 255) / 256);
-    hipLaunchKernelGGL((k_narrow2<T>), dim3(g2), dim3(256), 0, st, S, what, W);
-    launch_check<T>(sc, S, qc, cnt, what, flags + off, st, false, plan, gs, gstride, W.hit);
+    hipLaunchKernelGGL((k_narrow2<T>), dim3(g2), dim3(256), 0, cs, S, what, W);
+    launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());
+  }
+  if (two) {
+    for (int k = 1; k < n_sets; k++) {
+      GH_HIP(hipEventRecord(sc->ev_join[k], sc->aux[k]));
+      GH_HIP(hipStreamWaitEvent(st, sc->ev_join[k], 0));
+    }
   }
   return GH_OK;
 }
@@ -377,6 +420,12 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
                            : build_and_upload<double>(sc, *robot, *obstacles, margin, sc->s64);
       if (rc == GH_OK && hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(GH_ERR_HIP, "hipStreamCreate failed");
+      if (rc == GH_OK && hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming) != hipSuccess)
+        rc = fail(GH_ERR_HIP, "hipEventCreate failed");
+      for (int k = 1; k < kMaxSets && rc == GH_OK; k++)
+        if (hipStreamCreateWithFlags(&sc->aux[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sc->ev_join[k], hipEventDisableTiming) != hipSuccess)
+          rc = fail(GH_ERR_HIP, "hipStreamCreate failed");
       if (rc == GH_OK) {
         if (hipMalloc((void**)&sc->counters, sizeof(CountersDev)) != hipSuccess ||
             hipMemset(sc->counters, 0, sizeof(CountersDev)) != hipSuccess)
@@ -402,8 +451,15 @@ void gh_scene_destroy(gh_scene* sc) {
     for (void* p : sc->tables) (void)hipFree(p);
     if (sc->counters) (void)hipFree(sc->counters);
     sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
-    sc->p_hdr.release(); sc->p_codes.release(); sc->p_qpose.release(); sc->p_hit.release(); sc->p_exact.release();
-    sc->p_pc.release(); sc->p_pstore.release();
+    for (int k = 1; k < kMaxSets; k++) {
+      if (sc->aux[k]) { (void)hipStreamSynchronize(sc->aux[k]); (void)hipStreamDestroy(sc->aux[k]); }
+      if (sc->ev_join[k]) (void)hipEventDestroy(sc->ev_join[k]);
+    }
+    if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+    for (auto& b : sc->pw) {
+      b.hdr.release(); b.items.release(); b.hit.release(); b.exact.release();
+      b.pc.release(); b.pstore.release();
+    }
   }
   delete sc;
 }
@@ -459,13 +515,17 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   out[0] = out[1] = out[2] = out[3] = 0;
-  if (!sc->p_pc.p) return GH_OK;
+  if (!sc->pw[0].pc.p) return GH_OK;
   GH_HIP(hipDeviceSynchronize());
-  PipeCounters h;
-  GH_HIP(hipMemcpy(&h, sc->p_pc.p, sizeof(h), hipMemcpyDeviceToHost));
-  out[0] = h.candidates;
-  out[1] = h.exact;
-  out[2] = h.overflow;
+  for (int k = 0; k < sc->last_sets; k++) {  // the last chunk of each workspace set the last call used
+    gh_scene::PipeBufs& b = sc->pw[k];
+    if (!b.pc.p) continue;
+    PipeCounters h;
+    GH_HIP(hipMemcpy(&h, b.pc.p, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] += h.candidates;
+    out[1] += h.exact;
+    out[2] += h.overflow;
+  }
   out[3] = sc->item_cap;
   return GH_OK;
 }

@@ -47,14 +47,50 @@ struct PipeCounters {
 // layout of one launch chunk's workspace
 template <class T> struct PipeWs {
   WaveHdr* hdr;          // [waves]
-  unsigned* codes;       // [waves][cap]
-  T* qpose;              // [waves][7][cap]  world pose of an env item's robot shape
+  T* items;              // [waves][cap] records of 8 T: {code, world pose (t, q) of an env item's robot shape}
   unsigned* hit;         // [configs]
   unsigned* exact;       // [cap2]  wave << kItemBits | item
   PipeCounters* pc;
   T* pstore;             // [L][7][stride]  every shape pose (self pairs only)
   size_t stride;
   unsigned cap, cap2;
+};
+
+// One survivor = one 8-element record (32 B in f32, 64 B in f64), written and read with 16-byte
+// accesses: consecutive queue slots are consecutive records, so both the sweep's pushes and the narrow
+// phase's fetches touch whole 32-byte sectors.  Element 0 carries the item code (bit pattern); a self
+// item has only its code (its two poses come from the pose store).
+template <class T> struct ItemIO;
+template <> struct ItemIO<float> {
+  GD static void store(float* rec, unsigned code, const Pose<float>& p) {
+    uint4* r = reinterpret_cast<uint4*>(rec);
+    r[0] = make_uint4(code, __float_as_uint(p.t.x), __float_as_uint(p.t.y), __float_as_uint(p.t.z));
+    r[1] = make_uint4(__float_as_uint(p.r.i), __float_as_uint(p.r.j), __float_as_uint(p.r.k), __float_as_uint(p.r.w));
+  }
+  GD static void store_code(float* rec, unsigned code) { *reinterpret_cast<unsigned*>(rec) = code; }
+  GD static unsigned code(const float* rec) { return *reinterpret_cast<const unsigned*>(rec); }
+  GD static Pose<float> pose(const float* rec) {
+    const uint4* r = reinterpret_cast<const uint4*>(rec);
+    const uint4 a = r[0], b = r[1];
+    return {{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)},
+            {__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)}};
+  }
+};
+template <> struct ItemIO<double> {
+  GD static void store(double* rec, unsigned code, const Pose<double>& p) {
+    double2* r = reinterpret_cast<double2*>(rec);
+    r[0] = make_double2(__longlong_as_double((long long)code), p.t.x);
+    r[1] = make_double2(p.t.y, p.t.z);
+    r[2] = make_double2(p.r.i, p.r.j);
+    r[3] = make_double2(p.r.k, p.r.w);
+  }
+  GD static void store_code(double* rec, unsigned code) { *reinterpret_cast<unsigned*>(rec) = code; }
+  GD static unsigned code(const double* rec) { return *reinterpret_cast<const unsigned*>(rec); }
+  GD static Pose<double> pose(const double* rec) {
+    const double2* r = reinterpret_cast<const double2*>(rec);
+    const double2 a = r[0], b = r[1], c = r[2], d = r[3];
+    return {{a.y, b.x, b.y}, {c.x, c.y, d.x, d.y}};
+  }
 };
 
 __device__ __forceinline__ unsigned lane_rank(unsigned long long b) {
@@ -107,8 +143,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
   const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
   const bool dbg_no_sweep = (what & 0x800u) != 0, dbg_no_push = (what & 0x400u) != 0;  // profiling ablations
 
-  unsigned* codes = W.codes + wave * W.cap;
-  T* qpose = W.qpose + wave * 7 * (size_t)W.cap;
+  T* items = W.items + wave * 8 * (size_t)W.cap;
   unsigned count = 0;  // wave-uniform
   bool overflow = false;
 
@@ -201,10 +236,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
           while (mm != 0) {
             const int z = __clz(mm);  // bit 31 - z  <->  obstacle o0 + z
             mm &= ~(0x80000000u >> z);
-            codes[pos] = ((unsigned)(o0 + z) << 16) | ((unsigned)(s0 + j) << 6) | (unsigned)lane;
-            T* b = qpose + pos;
-            b[0] = P[j].t.x; b[W.cap] = P[j].t.y; b[2 * W.cap] = P[j].t.z;
-            b[3 * W.cap] = P[j].r.i; b[4 * W.cap] = P[j].r.j; b[5 * W.cap] = P[j].r.k; b[6 * W.cap] = P[j].r.w;
+            ItemIO<T>::store(items + (size_t)pos * 8, ((unsigned)(o0 + z) << 16) | ((unsigned)(s0 + j) << 6) | (unsigned)lane, P[j]);
             pos++;
           }
         }
@@ -259,7 +291,7 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
         while (m != 0) {
           const int z = __clz(m);
           m &= ~(0x80000000u >> z);
-          codes[pos++] = 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane;
+          ItemIO<T>::store_code(items + (size_t)(pos++) * 8, 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane);
         }
       }
       count += tot;
@@ -285,10 +317,16 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
 // obstacle, the lane looks up the grid cell its shape centre falls in (one grid per class of shape
 // radius, built on the host: gear_scene.hpp build_grids) and tests only the obstacles listed there.
 // Shapes are handled one at a time as the FK walk produces them, so no pose has to stay in
-// registers; survivors take their queue slot from an LDS counter.  With self pairs every shape pose
-// goes to the pose store.  Same queue format as k_sweep; the flags are identical because every pair
-// whose bounding spheres overlap is listed (conservative lists), and pairs that do not cannot collide.
+// registers.  A cell's list is a chain of 16-byte blocks of eight obstacle indices: ONE load brings a
+// lane's whole list (almost always), the eight cull records are then fetched together, and the
+// survivors of the block take consecutive queue slots from ballot prefix sums (no atomics).  Per
+// shape that is two dependent memory round trips, not two per candidate.  With self pairs every shape
+// pose goes to the pose store.  Same queue format as k_sweep; the flags are identical because every
+// pair whose bounding spheres overlap is listed (conservative lists), and pairs that do not cannot
+// collide.
 // ---------------------------------------------------------------------------
+template <class T> struct alignas(16) Cull4 { T x, y, z, r; };
+
 template <class T>
 __global__ void __launch_bounds__(kWave)
 k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres, int max_node) {
@@ -300,11 +338,9 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
   const bool live = col < n;
   const size_t i = live ? col : n - 1;
   const T* qrow = q + i * (size_t)S.n_cols;
-  unsigned* cnt = reinterpret_cast<unsigned*>(gear_lds);  // queue fill of this wave
-  const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds + 16), (size_t)kWave, (size_t)lane};
-  T* cen = reinterpret_cast<T*>(gear_lds + 16 + (size_t)S.n_slots * 7 * kWave * sizeof(T));  // [L][3][64]
+  const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)lane};
+  T* cen = reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T));  // [L][3][64]
   (void)max_node;  // this kernel is light on registers: half-angle sin/cos are computed inside the walk
-  if (lane == 0) *cnt = 0u;
 
   const bool ok = limits_ok(S, V, qrow);
   const bool do_env = (what & 1u) && S.n_obs > 0;
@@ -312,17 +348,17 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
   const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
   const bool dbg_no_sweep = (what & 0x800u) != 0;
 
-  unsigned* codes = W.codes + wave * W.cap;
-  T* qpose = W.qpose + wave * 7 * (size_t)W.cap;
+  T* items = W.items + wave * 8 * (size_t)W.cap;
   const GEAR_CAS GridDev<T>* grids = to_cas(S.grids);
   const GEAR_CAS int32_t* shape_grid = to_cas(S.shape_grid);
-  const uint32_t* __restrict__ cell_off = S.cell_off;
-  const uint16_t* __restrict__ cell_items = S.cell_items;
-  const T* __restrict__ ocull = S.ocull;
+  const uint4* __restrict__ blocks = reinterpret_cast<const uint4*>(S.cell_blk);
+  const Cull4<T>* __restrict__ ocull = reinterpret_cast<const Cull4<T>*>(S.ocull);
+  const unsigned sentinel = (unsigned)S.n_obs;
 
   const int n_walk = (do_env || do_self) ? S.n_shapes : 0;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  unsigned count = 0;  // wave-uniform
+  bool overflow = false;
+  unsigned long long ncand = 0;
 
   int node = -1;
   Pose<T> cur{{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
@@ -350,38 +386,53 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
     const GEAR_CAS GridDev<T>* g = grids + shape_grid[s];
     const T fx = (ws.t.x - g->org[0]) * g->inv_h, fy = (ws.t.y - g->org[1]) * g->inv_h, fz = (ws.t.z - g->org[2]) * g->inv_h;
     const bool inside = push_ok && fx >= T(0) && fy >= T(0) && fz >= T(0) && fx < T(g->nx) && fy < T(g->ny) && fz < T(g->nz);
-    unsigned k = 0, e = 0;
-    if (inside) {
-      const unsigned cell = (unsigned)g->off_base + ((unsigned)(int)fz * (unsigned)g->ny + (unsigned)(int)fy) * (unsigned)g->nx + (unsigned)(int)fx;
-      k = cell_off[cell];
-      e = cell_off[cell + 1];
-    }
+    unsigned blk = 0;  // block 0 is the empty list
+    if (inside) blk = (unsigned)g->off_base + ((unsigned)(int)fz * (unsigned)g->ny + (unsigned)(int)fy) * (unsigned)g->nx + (unsigned)(int)fx;
     const T rho = sh->br;
-    if (what & 0x8000u) atomicAdd(&W.pc->candidates, (unsigned long long)(e - k));  // diagnostic count
-    auto test_push = [&](bool valid, unsigned o, T ox, T oy, T oz, T orad) {
-      const T dx = ws.t.x - ox, dy = ws.t.y - oy, dz = ws.t.z - oz;
-      const T rr = rho + orad;
-      if (valid && dx * dx + dy * dy + dz * dz < rr * rr) {
-        const unsigned pos = atomicAdd(cnt, 1u);
-        if (pos < W.cap) {
-          codes[pos] = (o << 16) | ((unsigned)s << 6) | (unsigned)lane;
-          T* b = qpose + pos;
-          b[0] = ws.t.x; b[W.cap] = ws.t.y; b[2 * W.cap] = ws.t.z;
-          b[3 * W.cap] = ws.r.i; b[4 * W.cap] = ws.r.j; b[5 * W.cap] = ws.r.k; b[6 * W.cap] = ws.r.w;
-        }
+    const unsigned code_base = ((unsigned)s << 6) | (unsigned)lane;
+    bool more;
+    do {
+      const uint4 w = blocks[blk];
+      const bool cont = (w.w >> 31) != 0;
+      unsigned id[8] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, w.z >> 16, w.w & 0xffffu, w.w >> 16};
+      if (cont) id[6] = id[7] = sentinel;
+      Cull4<T> oc[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) oc[j] = ocull[id[j]];  // eight independent loads; a sentinel reads the far dummy
+      unsigned h = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const T dx = ws.t.x - oc[j].x, dy = ws.t.y - oc[j].y, dz = ws.t.z - oc[j].z;
+        const T rr = rho + oc[j].r;
+        h |= (dx * dx + dy * dy + dz * dz < rr * rr) ? (1u << j) : 0u;
       }
-    };
-    while (__ballot(k < e) != 0) {
-      const bool v0 = k < e;
-      const unsigned o0 = v0 ? cell_items[k] : 0u;
-      test_push(v0, o0, ocull[4 * o0], ocull[4 * o0 + 1], ocull[4 * o0 + 2], ocull[4 * o0 + 3]);
-      k++;
-    }
+      if (what & 0x8000u) {  // diagnostic count of the candidates
+#pragma unroll
+        for (int j = 0; j < 8; j++) ncand += id[j] != sentinel ? 1u : 0u;
+      }
+      const unsigned nl = (unsigned)__popc(h);
+      if (__ballot(nl != 0) != 0) {
+        unsigned off, tot;
+        wave_offsets(nl, off, tot);
+        if (count + tot > W.cap) {
+          overflow = true;
+        } else {
+          unsigned pos = count + off;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            if ((h >> j) & 1u) {
+              ItemIO<T>::store(items + (size_t)pos * 8, (id[j] << 16) | code_base, ws);
+              pos++;
+            }
+          }
+        }
+        count += tot;
+      }
+      blk = cont ? (w.w & 0x7fffffffu) : 0u;
+      more = __ballot(cont) != 0;
+    } while (more);
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  unsigned count = *cnt;  // wave-uniform
-  bool overflow = count > W.cap;
+  if (what & 0x8000u) atomicAdd(&W.pc->candidates, ncand);
 
   // ---- self shape pairs (as in k_sweep, poses already in the pose store) --------------------------
   if (do_self) {
@@ -418,7 +469,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
         while (m != 0) {
           const int z = __clz(m);
           m &= ~(0x80000000u >> z);
-          codes[pos++] = 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane;
+          ItemIO<T>::store_code(items + (size_t)(pos++) * 8, 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane);
         }
       }
       count += tot;
@@ -433,7 +484,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
 template <class T>
 __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>& V, const PipeWs<T>& W, size_t wave,
                                            unsigned j, unsigned code, ShapeRef<T>& A, Pose<T>& wa, ShapeRef<T>& B,
-                                           Pose<T>& wb) {
+                                           Pose<T>& wb, unsigned dbg = 0) {
   if (code >> 31) {
     const int pi = (code >> 6) & 0x1ffffff;
     const int s1 = V.spairs[4 * pi], s2 = V.spairs[4 * pi + 1];
@@ -445,10 +496,11 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
     B = shape_ref<T>(V.rshapes + s2);
     wb = {{b[0], b[W.stride], b[2 * W.stride]}, {b[3 * W.stride], b[4 * W.stride], b[5 * W.stride], b[6 * W.stride]}};
   } else {
-    const int s = (code >> 6) & 1023, o = (code >> 16) & 32767;
-    const T* a = W.qpose + wave * 7 * (size_t)W.cap + j;
+    const int s = (code >> 6) & 1023;
+    int o = (code >> 16) & 32767;
+    if (dbg & 0x10000u) o &= 3;  // profiling ablation: four distinct obstacle records (results are wrong)
     A = shape_ref<T>(V.rshapes + s);
-    wa = {{a[0], a[W.cap], a[2 * W.cap]}, {a[3 * W.cap], a[4 * W.cap], a[5 * W.cap], a[6 * W.cap]}};
+    wa = ItemIO<T>::pose(W.items + (wave * (size_t)W.cap + j) * 8);
     B = shape_ref<T>(V.oshapes + o);
     wb = shape_pose<T>(V.oshapes + o);
   }
@@ -480,7 +532,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   if (tid < 4) hits[tid] = 0;
   if (tid == 4) en = 0;
   __syncthreads();
-  const unsigned* codes = W.codes + wave * W.cap;
+  const T* items = W.items + wave * 8 * (size_t)W.cap;
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   bool redo = false;  // the exact queue ran full (uniform over the workgroup)
@@ -488,7 +540,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   for (unsigned base = 0; base < h.count; base += kN1Threads) {
     const unsigned j = base + tid;
     bool valid = j < h.count;
-    const unsigned code = valid ? codes[j] : 0u;
+    const unsigned code = valid ? ItemIO<T>::code(items + (size_t)j * 8) : 0u;
     const int ln = code & 63;
     const bool sf = (code >> 31) != 0;
     if (valid) {
@@ -500,7 +552,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     if (valid) {
       ShapeRef<T> A, B;
       Pose<T> wa, wb;
-      item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
+      item_fetch(S, V, W, wave, j, code, A, wa, B, wb, what);
       r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
       if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
     }
@@ -556,7 +608,7 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
     const unsigned ent = W.exact[e];
     const size_t wave = ent >> kItemBits;
     const unsigned j = ent & (unsigned)(kMaxItemCap - 1);
-    const unsigned code = W.codes[wave * W.cap + j];
+    const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
     const size_t cfg = wave * kWave + (code & 63u);
     const unsigned bit = (code >> 31) ? 2u : 1u;
     if (W.hit[cfg] & (bit | kHitRedo)) continue;

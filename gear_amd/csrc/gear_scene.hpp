@@ -8,6 +8,7 @@
 //   urdf_geometry_to_shape_handle                    src/collision/urdf.rs:10-73
 //   Compound<f64>::from_urdf_robot                   src/collision/collision_checker.rs:349-369
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -33,8 +34,7 @@ struct HostTables {
   std::vector<T> verts, planes;
   std::vector<GridDev<T>> grids;
   std::vector<int32_t> shape_grid;
-  std::vector<uint32_t> cell_off;
-  std::vector<uint16_t> cell_items;
+  std::vector<uint32_t> cell_blk;  // [n_blocks][4], see SceneDev::cell_blk
   int n_slots = 0;
   T margin = 0;
 };
@@ -225,12 +225,20 @@ inline void build_grids(HostTables<T>& H, double margin) {
   const size_t O = H.oshapes.size(), L = H.rshapes.size();
   H.shape_grid.assign(L, 0);
   if (O < 32 || L == 0) return;  // small fields are swept directly
+  {
+    const uint32_t sentinel = (uint32_t)O, empty = sentinel | (sentinel << 16);
+    H.cell_blk.assign(4, empty);  // block 0: the empty list
+  }
   std::vector<double> radii;
   for (auto& s : H.rshapes) radii.push_back((double)s.br);
   std::vector<double> sorted = radii;
   std::sort(sorted.begin(), sorted.end());
   sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
-  const int n_cls = (int)std::min<size_t>(4, sorted.size());
+  const char* e_cls = getenv("GEAR_HIP_GRID_CLASSES");  // tuning aids
+  const char* e_h = getenv("GEAR_HIP_GRID_H");
+  const size_t max_cls = e_cls ? (size_t)std::max(1, atoi(e_cls)) : 4;
+  const double h_scale = e_h ? std::max(0.05, atof(e_h)) : 1.0;
+  const int n_cls = (int)std::min<size_t>(max_cls, sorted.size());
   std::vector<double> cls_r(n_cls);
   for (int c = 0; c < n_cls; c++) cls_r[c] = sorted[(size_t)((c + 1) * sorted.size() / n_cls) - 1];
   for (size_t s = 0; s < L; s++) {
@@ -254,7 +262,7 @@ inline void build_grids(HostTables<T>& H, double margin) {
     const double slack = 1e-5 + 2e-6 * (ext + std::fabs(lo[0]) + std::fabs(lo[1]) + std::fabs(lo[2]));
     std::vector<double> sr(reach);
     std::sort(sr.begin(), sr.end());
-    const double h = std::max({ext / 48.0, 0.5 * sr[O / 2], 0.02});
+    const double h = std::max({ext / 48.0, 0.5 * sr[O / 2], 0.02}) * h_scale;
     GridDev<T> g;
     int n[3];
     for (int k = 0; k < 3; k++) {
@@ -264,7 +272,7 @@ inline void build_grids(HostTables<T>& H, double margin) {
     }
     g.inv_h = T(1.0 / h);
     g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
-    g.off_base = (int32_t)H.cell_off.size();
+    g.off_base = (int32_t)(H.cell_blk.size() / 4);
     const size_t ncell = (size_t)n[0] * n[1] * n[2];
     // the device computes floor((p - org) * inv_h) with ITS org and inv_h: use the same rounded values
     const double orgd[3] = {(double)g.org[0], (double)g.org[1], (double)g.org[2]}, hd = 1.0 / (double)g.inv_h;
@@ -290,11 +298,28 @@ inline void build_grids(HostTables<T>& H, double margin) {
             if (d2 <= r * r) cells[((size_t)iz * n[1] + iy) * n[0] + ix].push_back((uint16_t)o);
           }
     }
+    // head blocks first (one per cell, contiguous), overflow blocks of this grid after them
+    const uint32_t sentinel = (uint32_t)O, empty = sentinel | (sentinel << 16);
+    const size_t base = H.cell_blk.size() / 4;
+    H.cell_blk.resize((base + ncell) * 4, empty);
     for (size_t i = 0; i < ncell; i++) {
-      H.cell_off.push_back((uint32_t)H.cell_items.size());
-      H.cell_items.insert(H.cell_items.end(), cells[i].begin(), cells[i].end());
+      const std::vector<uint16_t>& list = cells[i];
+      size_t cur = base + i, pos = 0;
+      for (;;) {
+        const size_t left = list.size() - pos;
+        const size_t take = left <= 8 ? left : 6;
+        for (size_t j = 0; j < take; j++) {
+          uint32_t& w = H.cell_blk[cur * 4 + j / 2];
+          w = (j & 1) ? ((w & 0xffffu) | ((uint32_t)list[pos + j] << 16)) : ((w & 0xffff0000u) | list[pos + j]);
+        }
+        pos += take;
+        if (pos == list.size()) break;
+        const size_t nb = H.cell_blk.size() / 4;
+        H.cell_blk.resize((nb + 1) * 4, empty);
+        H.cell_blk[cur * 4 + 3] = 0x80000000u | (uint32_t)nb;
+        cur = nb;
+      }
     }
-    H.cell_off.push_back((uint32_t)H.cell_items.size());
     H.grids.push_back(g);
   }
 }
@@ -419,6 +444,8 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
   for (size_t i = 0; i < cull_rec.size(); i++)
     for (int comp = 0; comp < 5; comp++) H.ocullq[(i / 4) * 20 + comp * 4 + (i % 4)] = T(cull_rec[i][comp]);
   detail::build_grids<T>(H, std::max(margin, 0.0));
+  // the cell lists' sentinel index n_obs: a record no robot shape can reach
+  H.ocull.insert(H.ocull.end(), {T(1e18), T(0), T(0), T(0)});
   // self pairs -> shape ranges; a pair whose joint has no model never yields
   // (collision_checker.rs:150-159)
   for (int p = 0; p < r.n_pairs; p++) {

@@ -70,7 +70,7 @@ struct GridDev {
   T org[3];        // world position of the grid's low corner
   T inv_h;         // 1 / cell size
   int32_t nx, ny, nz;
-  int32_t off_base;  // first entry of this grid in cell_off[] (nx*ny*nz + 1 entries)
+  int32_t off_base;  // block index of this grid's cell (0,0,0) in cell_blk[] (nx*ny*nz head blocks)
 };
 
 struct CountersDev {
@@ -88,7 +88,7 @@ struct SceneDev {
   const LimitDev<T>* limits;
   const ShapeDev<T>* rshapes;
   const ShapeDev<T>* oshapes;
-  const T* ocull;  // [n_obs][4]: world bounding sphere cx,cy,cz and radius + margin (pre-inflated)
+  const T* ocull;  // [n_obs + 1][4]: world bounding sphere cx,cy,cz and radius + margin (pre-inflated); last = far dummy
   // cull records for the batched kernels in quads of 4 obstacles, component-major inside a quad:
   // [n_obs_pad / 4][5][4] = -2cx, -2cy, -2cz, -2R, k  with R = obstacle radius + margin (inflated) and
   // k = |c|^2 - R^2 - tau; n_obs_pad is a multiple of 32 (tail = far dummies).  Then
@@ -105,8 +105,11 @@ struct SceneDev {
   // broadphase grids (n_grids == 0: none built)
   const GridDev<T>* grids;      // [n_grids]
   const int32_t* shape_grid;    // [n_shapes] grid of each robot shape
-  const uint32_t* cell_off;     // CSR offsets into cell_items, all grids concatenated
-  const uint16_t* cell_items;   // obstacle indices
+  // Cell lists as chains of 16-byte blocks of eight 16-bit obstacle indices (unused slots hold the
+  // sentinel n_obs, whose ocull record is a far dummy).  Bit 31 of a block's last dword set: the block
+  // holds six indices and the low 31 bits are the index of the next block.  Block 0 is empty (lanes
+  // outside a grid read it); a grid's head blocks are contiguous from off_base, one per cell.
+  const uint32_t* cell_blk;     // [n_blocks][4]
   int32_t n_grids, pad4;
 };
 

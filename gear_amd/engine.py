@@ -33,9 +33,10 @@ class GearHipError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise GearHipError(-3, f"{LIB_PATH} is missing: run `python -m gear_amd.build` (no CPU fallback exists)")
-        L = C.CDLL(LIB_PATH)
+        path = os.environ.get("GEAR_HIP_LIB", LIB_PATH)   # another build of the same library (A/B measurements)
+        if not os.path.exists(path):
+            raise GearHipError(-3, f"{path} is missing: run `python -m gear_amd.build` (no CPU fallback exists)")
+        L = C.CDLL(path)
         vp, sz, u32, u8 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8
         L.gh_scene_create.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int, C.POINTER(vp)]
         L.gh_scene_destroy.argtypes = [vp]

@@ -19,7 +19,10 @@
  *    optional hipStream_t (as void*), the others take host pointers and are
  *    synchronous;
  *  - a gh_scene is immutable after creation and may be shared by host threads
- *    (calls on one scene serialise on the scene's stream);
+ *    (calls on one scene serialise on the scene's stream).  A scene owns one
+ *    device workspace: asynchronous `_dev` calls on the SAME scene must all be
+ *    enqueued on the same stream (or be ordered by the caller); use one scene
+ *    per stream for concurrent launches;
  *  - scalars in descriptors are f64; `precision` (32|64) selects the arithmetic
  *    type T of the whole path, converting exactly where the reference converts
  *    (na::convert of URDF f64 values, src/collision/urdf.rs:18-27).
@@ -210,8 +213,8 @@ int gh_self_hits(gh_scene* scene, const void* q, size_t n, uint64_t* pair_mask);
 int gh_check_batch_counted(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
                            uint8_t* flags_dev, gh_counters* out);
 
-/* Diagnostic, no counterpart in the reference: counters of the LAST chunk of the last large-batch call
- * on this scene (synchronises the device).  out[0] broadphase candidates tested (only when `what`
+/* Diagnostic, no counterpart in the reference: counters of the last large-batch call on this
+ * scene, summed over the last chunk of each of its (one or two) workspace sets (synchronises the device).  out[0] broadphase candidates tested (only when `what`
  * carried GH_COUNT_CANDIDATES), out[1] items that needed the exact stage, out[2] != 0 when the exact
  * queue overflowed (those configurations were re-checked), out[3] survivor-queue capacity per wave. */
 int gh_pipeline_last_stats(gh_scene* scene, uint64_t out[4]);
