@@ -124,6 +124,10 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.spairs, &S.spairs))) return rc;
   if ((rc = upload(sc, H.spair_r, &S.spair_r))) return rc;
   S.n_spairs = (int)H.spair_r.size();
+  S.n_first = H.n_first;
+  if ((rc = upload(sc, H.sp_first_slot, &S.sp_first_slot))) return rc;
+  if ((rc = upload(sc, H.sp_late_off, &S.sp_late_off))) return rc;
+  if ((rc = upload(sc, H.sp_late, &S.sp_late))) return rc;
   if ((rc = upload(sc, H.verts, &S.verts))) return rc;
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
   if ((rc = upload(sc, H.grids, &S.grids))) return rc;
@@ -269,6 +273,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const bool two = n_sets > 1;
   const size_t waves = chunk / kWave;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
+  // the grid sweep keeps the pose of every shape that is the earlier one of a self pair in LDS and
+  // writes self survivors with both poses inline: no pose store
+  const size_t first_bytes = do_self ? (size_t)S.n_first * 7 * kWave * sizeof(T) : 0;
+  const bool use_grid = S.n_grids > 0 && (what & 1u) && !(what & kNoGrid) && first_bytes <= 24 * 1024;
   PipeWs<T> Ws[kMaxSets];
   int rc;
   for (int k = 0; k < n_sets; k++) {
@@ -281,7 +289,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     if ((rc = b.hdr.ensure(waves * sizeof(WaveHdr))) || (rc = b.items.ensure(waves * W.cap * 8 * sizeof(T))) ||
         (rc = b.hit.ensure(chunk * 4)) ||
         (rc = b.exact.ensure((size_t)W.cap2 * 4)) || (rc = b.pc.ensure(sizeof(PipeCounters))) ||
-        (do_self && (rc = b.pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
+        (do_self && !use_grid && (rc = b.pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
       return rc;
     W.hdr = (WaveHdr*)b.hdr.p;
     W.items = (T*)b.items.p;
@@ -305,7 +313,6 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const size_t sc_bytes = (size_t)(max_node + 1) * 2 * kWave * sizeof(T);
   const size_t lds = slot_bytes + sc_bytes + (lds_centres ? cen_bytes : 0);
   const int K = pick_chunk(sc->L);
-  const bool use_grid = S.n_grids > 0 && (what & 1u) && !(what & kNoGrid);
   if (two) {
     GH_HIP(hipEventRecord(sc->ev_fork, st));
     for (int k = 1; k < n_sets; k++) GH_HIP(hipStreamWaitEvent(sc->aux[k], sc->ev_fork, 0));
@@ -320,8 +327,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
     if (use_grid) {
       static const size_t lds_pad = [] { const char* e = getenv("GEAR_HIP_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-      hipLaunchKernelGGL((k_sweep_grid<T>), dim3(grid_for(cnt)), dim3(kWave), lds - sc_bytes + lds_pad, cs, S, qc, cnt, what, W, lds_centres,
-                         max_node);
+      hipLaunchKernelGGL((k_sweep_grid<T>), dim3(grid_for(cnt)), dim3(kWave), slot_bytes + first_bytes + lds_pad, cs, S, qc, cnt, what, W);
     } else {
       switch (K) {
         case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;

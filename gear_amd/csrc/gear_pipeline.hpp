@@ -31,6 +31,9 @@ constexpr int kExLds = 512;           // per-workgroup staging of exact entries 
 constexpr int kItemBits = 13;          // an exact entry packs (wave << kItemBits) | item index
 constexpr int kMaxItemCap = 1 << kItemBits;
 
+constexpr unsigned kSelfInline = 0xc0000000u;  // self item whose two poses are in its own and the next record
+constexpr unsigned kItemSkip = 0xffffffffu;    // second record of such an item: not an item
+
 struct WaveHdr {
   unsigned count;     // items pushed by the wave (may exceed the capacity: then `overflow` is set)
   unsigned limit_lo;  // lanes whose configuration violates a joint limit
@@ -329,7 +332,7 @@ template <class T> struct alignas(16) Cull4 { T x, y, z, r; };
 
 template <class T>
 __global__ void __launch_bounds__(kWave)
-k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres, int max_node) {
+k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
   const int lane = threadIdx.x;
@@ -339,8 +342,11 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
   const size_t i = live ? col : n - 1;
   const T* qrow = q + i * (size_t)S.n_cols;
   const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)lane};
-  T* cen = reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T));  // [L][3][64]
-  (void)max_node;  // this kernel is light on registers: half-angle sin/cos are computed inside the walk
+  // poses of the shapes that are the earlier one of a self pair: [n_first][7][64]
+  const PoseStore<T> first{reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T)), (size_t)kWave, (size_t)lane};
+  const GEAR_CAS int32_t* sp_first_slot = to_cas(S.sp_first_slot);
+  const GEAR_CAS int32_t* sp_late_off = to_cas(S.sp_late_off);
+  const GEAR_CAS int32_t* sp_late = to_cas(S.sp_late);
 
   const bool ok = limits_ok(S, V, qrow);
   const bool do_env = (what & 1u) && S.n_obs > 0;
@@ -371,15 +377,33 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
     }
     const Pose<T> ws = pose_mul(cur, shape_pose<T>(sh));
     if (do_self) {
-      if (live) {
-        T* b = W.pstore + (size_t)s * 7 * W.stride + col;
-        b[0] = ws.t.x; b[W.stride] = ws.t.y; b[2 * W.stride] = ws.t.z;
-        b[3 * W.stride] = ws.r.i; b[4 * W.stride] = ws.r.j; b[5 * W.stride] = ws.r.k; b[6 * W.stride] = ws.r.w;
+      // self shape pairs whose later shape is s: its pose is live, the other one's waits in LDS.  A
+      // survivor takes two queue records, {code, pose of the pair's first shape} and {skip, pose of its
+      // second shape}: nothing else has to be kept for the narrow phase.
+      for (int e = sp_late_off[s]; e < sp_late_off[s + 1]; e++) {
+        const int p = sp_late[e];
+        const int s1 = V.spairs[4 * p], s2 = V.spairs[4 * p + 1];
+        const int other = s1 == s ? s2 : s1;
+        Pose<T> po = ws;
+        if (other != s) po = first.get(sp_first_slot[other]);
+        const V3<T> d = ws.t - po.t;  // (c1 - c2) or (c2 - c1): the squares are the same
+        const T rr = V.spair_r[p];
+        const bool hit = push_ok && dot(d, d) < rr * rr;
+        const unsigned long long hb = __ballot(hit);
+        if (hb == 0) continue;
+        const unsigned tot = 2u * (unsigned)__popcll(hb);
+        if (count + tot > W.cap) {
+          overflow = true;
+        } else if (hit) {
+          const unsigned pos = count + 2u * lane_rank(hb);
+          const bool s_first = s1 == s;  // s is the pair's first shape
+          ItemIO<T>::store(items + (size_t)pos * 8, kSelfInline | ((unsigned)p << 6) | (unsigned)lane, s_first ? ws : po);
+          ItemIO<T>::store(items + (size_t)(pos + 1) * 8, kItemSkip, s_first ? po : ws);
+        }
+        count += tot;
       }
-      if (lds_centres) {
-        T* cc = cen + (size_t)s * 3 * kWave + lane;
-        cc[0] = ws.t.x; cc[kWave] = ws.t.y; cc[2 * kWave] = ws.t.z;
-      }
+      const int fs = sp_first_slot[s];
+      if (fs >= 0) first.put(fs, ws);
     }
     if (!do_env || dbg_no_sweep) continue;
     // ---- cell lookup ---------------------------------------------------------------------------
@@ -434,48 +458,6 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
   }
   if (what & 0x8000u) atomicAdd(&W.pc->candidates, ncand);
 
-  // ---- self shape pairs (as in k_sweep, poses already in the pose store) --------------------------
-  if (do_self) {
-    if (!lds_centres) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (int p0 = 0; p0 < S.n_spairs; p0 += 32) {
-      const int pc = min(32, S.n_spairs - p0);
-      unsigned m = 0;
-      for (int kk = 0; kk < pc; kk++) {
-        const int s1 = V.spairs[4 * (p0 + kk)], s2 = V.spairs[4 * (p0 + kk) + 1];
-        V3<T> c1, c2;
-        if (lds_centres) {
-          const T* a = cen + (size_t)s1 * 3 * kWave + lane;
-          const T* b = cen + (size_t)s2 * 3 * kWave + lane;
-          c1 = {a[0], a[kWave], a[2 * kWave]};
-          c2 = {b[0], b[kWave], b[2 * kWave]};
-        } else {
-          const T* a = W.pstore + (size_t)s1 * 7 * W.stride + (live ? col : 0);
-          const T* b = W.pstore + (size_t)s2 * 7 * W.stride + (live ? col : 0);
-          c1 = {a[0], a[W.stride], a[2 * W.stride]};
-          c2 = {b[0], b[W.stride], b[2 * W.stride]};
-        }
-        const V3<T> d = c1 - c2;
-        const T rr = V.spair_r[p0 + kk];
-        m |= (push_ok && dot(d, d) < rr * rr) ? (0x80000000u >> kk) : 0u;
-      }
-      const unsigned nl = (unsigned)__popc(m);
-      if (__ballot(nl != 0) == 0) continue;
-      unsigned off, tot;
-      wave_offsets(nl, off, tot);
-      if (count + tot > W.cap) {
-        overflow = true;
-      } else {
-        unsigned pos = count + off;
-        while (m != 0) {
-          const int z = __clz(m);
-          m &= ~(0x80000000u >> z);
-          ItemIO<T>::store_code(items + (size_t)(pos++) * 8, 0x80000000u | ((unsigned)(p0 + z) << 6) | (unsigned)lane);
-        }
-      }
-      count += tot;
-    }
-  }
-
   const unsigned long long bad = __ballot(live && !ok);
   if (lane == 0) W.hdr[wave] = {count, (unsigned)bad, (unsigned)(bad >> 32), overflow ? 1u : 0u};
 }
@@ -485,8 +467,16 @@ template <class T>
 __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>& V, const PipeWs<T>& W, size_t wave,
                                            unsigned j, unsigned code, ShapeRef<T>& A, Pose<T>& wa, ShapeRef<T>& B,
                                            Pose<T>& wb, unsigned dbg = 0) {
-  if (code >> 31) {
-    const int pi = (code >> 6) & 0x1ffffff;
+  if ((code >> 30) == 3u) {
+    const int pi = (code >> 6) & 0xffffff;
+    const int s1 = V.spairs[4 * pi], s2 = V.spairs[4 * pi + 1];
+    const T* rec = W.items + (wave * (size_t)W.cap + j) * 8;
+    A = shape_ref<T>(V.rshapes + s1);
+    wa = ItemIO<T>::pose(rec);
+    B = shape_ref<T>(V.rshapes + s2);
+    wb = ItemIO<T>::pose(rec + 8);
+  } else if (code >> 31) {
+    const int pi = (code >> 6) & 0xffffff;
     const int s1 = V.spairs[4 * pi], s2 = V.spairs[4 * pi + 1];
     const size_t col = wave * kWave + (code & 63u);
     const T* a = W.pstore + (size_t)s1 * 7 * W.stride + col;
@@ -496,9 +486,11 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
     B = shape_ref<T>(V.rshapes + s2);
     wb = {{b[0], b[W.stride], b[2 * W.stride]}, {b[3 * W.stride], b[4 * W.stride], b[5 * W.stride], b[6 * W.stride]}};
   } else {
-    const int s = (code >> 6) & 1023;
+    int s = (code >> 6) & 1023;
     int o = (code >> 16) & 32767;
     if (dbg & 0x10000u) o &= 3;  // profiling ablation: four distinct obstacle records (results are wrong)
+    if (dbg & 0x20000u) o = __builtin_amdgcn_readfirstlane(o);  // ablation: one obstacle record per wave, scalar loads
+    if (dbg & 0x40000u) s = __builtin_amdgcn_readfirstlane(s);  // ablation: one robot record per wave
     A = shape_ref<T>(V.rshapes + s);
     wa = ItemIO<T>::pose(W.items + (wave * (size_t)W.cap + j) * 8);
     B = shape_ref<T>(V.oshapes + o);
@@ -541,6 +533,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     const unsigned j = base + tid;
     bool valid = j < h.count;
     const unsigned code = valid ? ItemIO<T>::code(items + (size_t)j * 8) : 0u;
+    valid = valid && code != kItemSkip;
     const int ln = code & 63;
     const bool sf = (code >> 31) != 0;
     if (valid) {

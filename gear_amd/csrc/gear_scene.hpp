@@ -35,6 +35,8 @@ struct HostTables {
   std::vector<GridDev<T>> grids;
   std::vector<int32_t> shape_grid;
   std::vector<uint32_t> cell_blk;  // [n_blocks][4], see SceneDev::cell_blk
+  std::vector<int32_t> sp_first_slot, sp_late_off, sp_late;  // see SceneDev
+  int n_first = 0;
   int n_slots = 0;
   T margin = 0;
 };
@@ -459,6 +461,25 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
         double rr = (double)H.rshapes[s1].br + (double)H.rshapes[s2].br + std::max(margin, 0.0);
         H.spair_r.push_back(T(rr * (1.0 + 1e-4) + 1e-9));
       }
+  }
+  // self shape pairs by their later shape (walk order = shape index order)
+  {
+    const size_t L = H.rshapes.size(), NP = H.spair_r.size();
+    H.sp_first_slot.assign(L, -1);
+    std::vector<std::vector<int32_t>> by_late(L);
+    for (size_t p = 0; p < NP; p++) {
+      const int s1 = H.spairs[4 * p], s2 = H.spairs[4 * p + 1];
+      by_late[(size_t)std::max(s1, s2)].push_back((int32_t)p);
+      if (s1 != s2) H.sp_first_slot[(size_t)std::min(s1, s2)] = 0;
+    }
+    H.n_first = 0;
+    for (size_t s = 0; s < L; s++)
+      if (H.sp_first_slot[s] == 0) H.sp_first_slot[s] = H.n_first++;
+    H.sp_late_off.assign(1, 0);
+    for (size_t s = 0; s < L; s++) {
+      H.sp_late.insert(H.sp_late.end(), by_late[s].begin(), by_late[s].end());
+      H.sp_late_off.push_back((int32_t)H.sp_late.size());
+    }
   }
   return true;
 }

@@ -99,7 +99,12 @@ struct SceneDev {
   const PairDev* pairs;
   const int32_t* spairs;  // [n_spairs][4]: s1, s2, node-pair index, 0
   const T* spair_r;       // [n_spairs]: inflated bounding-radius sum + margin
-  int32_t n_spairs, pad3;
+  int32_t n_spairs, n_first;
+  // self shape pairs grouped by the shape the FK walk reaches LATER (the sweep tests a pair when that
+  // shape's pose is live; the earlier shape's pose waits in an LDS slot)
+  const int32_t* sp_first_slot;  // [n_shapes] LDS pose slot of a shape that is the earlier one of some pair, else -1
+  const int32_t* sp_late_off;    // [n_shapes + 1] CSR offsets into sp_late
+  const int32_t* sp_late;        // [n_spairs] self shape pair indices
   const T* verts;   // [..][3]
   const T* planes;  // [..][4]
   // broadphase grids (n_grids == 0: none built)

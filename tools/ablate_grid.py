@@ -28,3 +28,7 @@ run(1 | PIPE | 0x300, "env, no narrow phase")
 run(1 | PIPE | 0xb00, "env, no narrow, no cell lookup (FK + finalize)")
 run(3 | PIPE | 0xb00, "env+self, no narrow, no cell lookup")
 run(3 | PIPE | 0x10100, "env+self, no exact, 4 distinct obstacle records")
+run(3 | PIPE | 0x20100, "env+self, no exact, wave-uniform obstacle record")
+run(3 | PIPE | 0x60100, "env+self, no exact, wave-uniform obstacle + robot")
+run(3 | PIPE | 0x300, "env+self, no narrow (again)")
+run(3 | PIPE | 0x80300, "env+self, no narrow, no pose store")
