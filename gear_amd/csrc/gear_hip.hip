@@ -276,7 +276,8 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   // the grid sweep keeps the pose of every shape that is the earlier one of a self pair in LDS and
   // writes self survivors with both poses inline: no pose store
   const size_t first_bytes = do_self ? (size_t)S.n_first * 7 * kWave * sizeof(T) : 0;
-  const bool use_grid = S.n_grids > 0 && (what & 1u) && !(what & kNoGrid) && first_bytes <= 24 * 1024;
+  const bool do_env = (what & 1u) && S.n_obs > 0;
+  const bool use_grid = (!do_env || S.n_grids > 0) && !(what & kNoGrid) && first_bytes <= 24 * 1024;  // self only: no lookup at all
   PipeWs<T> Ws[kMaxSets];
   int rc;
   for (int k = 0; k < n_sets; k++) {
