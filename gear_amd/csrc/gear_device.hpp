@@ -43,11 +43,40 @@ GD double t_sqrt(double x) { return sqrt(x); }
 // f32 joints take sin/cos through f64 and round once: the f32 reference (glibc/LLVM sinf, ~0.5 ulp)
 // and ocml's sincosf (~1-2 ulp) otherwise drift apart by a few 1e-7 over a 7-joint chain, which is
 // the whole 1e-6 pose budget.  7 f64 sincos per configuration are noise next to the pair tests.
+// The f64 evaluation only has to be good to ~1e-12 (it is rounded to f32 at once), so it is a short
+// one: two-term Cody-Waite reduction by pi/2 and the fdlibm kernel polynomials on [-pi/4, pi/4]
+// (|error| < 1e-15 there; the reduction adds < |x| * 2e-16).  Huge or non-finite arguments, which no
+// joint limit produces, take the library routine.
 GD void t_sincos(float x, float* s, float* c) {
-  double sd, cd;
-  sincos((double)x, &sd, &cd);
-  *s = (float)sd;
-  *c = (float)cd;
+  const double xd = (double)x;
+  if (!(fabs(xd) < 1.0e5)) {
+    double sd, cd;
+    sincos(xd, &sd, &cd);
+    *s = (float)sd;
+    *c = (float)cd;
+    return;
+  }
+  const double kf = rint(xd * 0.63661977236758134308);  // x * 2/pi
+  double r = fma(-kf, 1.57079632679489655800e+00, xd);
+  r = fma(-kf, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  double sn = fma(z * r, ps, r);
+  sn = xd == 0.0 ? xd : sn;  // sin(-0) = -0, as the library returns it
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int k = (int)kf;
+  const double ss = (k & 1) ? cs : sn, cc = (k & 1) ? sn : cs;
+  *s = (float)((k & 2) ? -ss : ss);
+  *c = (float)(((k + 1) & 2) ? -cc : cc);
 }
 GD void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 GD float t_atan2(float y, float x) { return atan2f(y, x); }
