@@ -157,6 +157,40 @@ def random_configs(chain: U.Chain, using: Sequence[int], n: int, seed: int = 0, 
     return (span2 * u + lo2).astype(dtype)
 
 
+def straight_edges_lockstep(chain: U.Chain, using: Sequence[int], n_edges: int, seed: int = 0, step: float = 0.1,
+                            min_len: int = 8, max_len: int = 64, dtype=np.float32):
+    """straight_edges for large edge counts: the same recurrence, advanced for all edges in lockstep
+    (one numpy step per sample index instead of one Python iteration per sample)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    lo, hi = joint_limits(chain, using)
+    d = len(using)
+    a = ((hi - lo) * rng.random((n_edges, d)) + lo).astype(dtype)
+    b = ((hi - lo) * rng.random((n_edges, d)) + lo).astype(dtype)
+    want = rng.integers(min_len, max_len + 1, size=n_edges)
+    stp = dtype(step)
+    base = a.copy()
+    alive = np.ones(n_edges, dtype=bool)
+    count = np.zeros(n_edges, dtype=np.int64)
+    rows = []          # (edge ids, samples) per step
+    for _ in range(max_len):
+        ids = np.nonzero(alive)[0]
+        if len(ids) == 0:
+            break
+        diff = b[ids] - base[ids]
+        dist = np.sqrt(np.sum(diff * diff, axis=1, dtype=dtype)).astype(dtype)
+        near = dist < stp
+        nxt = np.where(near[:, None], b[ids], base[ids] + diff * (stp / np.where(near, dtype(1), dist))[:, None]).astype(dtype)
+        base[ids] = nxt
+        rows.append((ids, nxt))
+        count[ids] += 1
+        alive[ids] = ~near & (count[ids] < want[ids])
+    off = np.concatenate([[0], np.cumsum(count)]).astype(np.uint32)
+    q = np.empty((int(off[-1]), d), dtype=dtype)
+    for k, (ids, smp) in enumerate(rows):
+        q[off[ids] + k] = smp
+    return q, off
+
+
 def straight_edges(chain: U.Chain, using: Sequence[int], n_edges: int, seed: int = 0, step: float = 0.1,
                    min_len: int = 8, max_len: int = 64, dtype=np.float32):
     """Edge samples as rrt's stepping produces them: from a random start, repeatedly
@@ -263,6 +297,9 @@ class Workload:
 
     def edges(self, n_edges, seed=0, dtype=np.float32, **kw):
         return straight_edges(self.chain, self.using, n_edges, seed, dtype=dtype, **kw)
+
+    def edges_lockstep(self, n_edges, seed=0, dtype=np.float32, **kw):
+        return straight_edges_lockstep(self.chain, self.using, n_edges, seed, dtype=dtype, **kw)
 
 
 def metric_workload(n_obstacles: int = 256, seed: int = 0, margin: float = 0.01) -> Workload:

@@ -1,0 +1,103 @@
+"""BASELINE.json's full sizes through the C ABI, checked by size-independent properties (the oracle
+needs ~10 ms per configuration, so it only spot-checks): the large-batch path — chunks rotating over
+several streams and workspace sets — must equal the fused kernel, commute with a permutation of the
+batch, not depend on chunk boundaries or on what the workspace held before, and first_bad must be the
+first flagged sample of every edge."""
+import os
+
+import numpy as np
+import pytest
+
+from gear_amd import descriptors as D
+from gear_amd import engine
+from gear_amd import workloads as W
+from oracle import binding as orc
+from tests.parity import compare_flags
+
+pytestmark = pytest.mark.gpu
+
+BOTH = D.GH_CHECK_ENV | D.GH_CHECK_SELF
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_metric_scene_multi_chunk_batch(prec):
+    """1M + 3 configurations of the metric scene: four chunks in flight, a ragged tail."""
+    w = W.metric_workload()
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    n = (1 << 20) + 3
+    q = w.configs(n, seed=31, dtype=hip.dtype, overshoot=0.005)
+    got = hip.check_batch(q, BOTH)                           # default path: pipeline, several streams
+    assert (got == hip.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
+    # a permutation of the batch permutes the flags (other chunk boundaries, other wave mates)
+    perm = np.random.default_rng(5).permutation(n)
+    assert (hip.check_batch(np.ascontiguousarray(q[perm]), BOTH) == got[perm]).all()
+    # a smaller call afterwards reuses the workspace sets: stale queue contents must not leak
+    m = 70001
+    assert (hip.check_batch(q[:m], BOTH) == got[:m]).all()
+    assert (hip.check_batch(q[:m], D.GH_CHECK_SELF) == (got[:m] & ~np.uint8(D.GH_FLAG_ENV))).all()
+    assert (hip.check_batch(q[:m], D.GH_CHECK_ENV) == (got[:m] & ~np.uint8(D.GH_FLAG_SELF))).all()
+    rates = [float(((got & b) != 0).mean()) for b in (1, 2, 4)]
+    assert rates[0] > 0.3 and rates[1] > 0.1 and rates[2] > 0.001, rates
+    # the oracle on a bounded sample spread over all chunks
+    ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    idx = np.linspace(0, n - 1, 192).astype(np.int64)
+    want, band = ora.check(np.ascontiguousarray(q[idx]), BOTH, threads=16)
+    rep = compare_flags(got[idx], want, band, prec)
+    assert rep["outside"] == 0, rep
+
+
+def test_config1_sample_urdf_1m(sample_robot, obstacles_robot):
+    """configs[1]: sample.urdf (8 columns, mimic gripper) vs obstacles.urdf, 1M random configurations."""
+    pairs = [("root", "l_wrist_yaw"), ("root", "l_wrist_pitch"), ("l_shoulder_yaw", "l_wrist_pitch")]
+    w = W.sample_workload(sample_robot, obstacles_robot, 0.01, self_pairs=pairs)
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    n = 1 << 20
+    q = w.configs(n, seed=0, overshoot=0.002)
+    got = hip.check_batch(q, BOTH)
+    assert (got == hip.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
+    assert 0.05 < ((got & 1) != 0).mean() < 0.4            # SURVEY 8d expects about 14 %
+    lim = (got & 4) != 0
+    assert lim.any() and (got[lim] == 4).all()             # a limit violation reports nothing else
+    ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    want, band = ora.check(q[:2000], BOTH, threads=16)
+    rep = compare_flags(got[:2000], want, band, 32)
+    assert rep["outside"] == 0, rep
+
+
+def test_config2_64k_edges():
+    """configs[2]: 64k straight segments of 8..64 samples (about 2.3M samples) in one gh_check_edges call."""
+    w = W.ur10_workload(256)
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    q, off = w.edges_lockstep(65536, seed=9, min_len=8, max_len=64)
+    assert len(q) > 2_000_000
+    bad = D.GH_FLAG_ENV | D.GH_FLAG_LIMIT
+    flags, first = hip.check_edges(q, off, D.GH_CHECK_ENV, bad)
+    hit = (flags & bad) != 0
+    # first_bad == first flagged sample of the edge, -1 if none (vectorised: running count of hits)
+    csum = np.concatenate([[0], np.cumsum(hit)])
+    any_hit = csum[off[1:]] > csum[off[:-1]]
+    pos = np.searchsorted(csum, csum[off[:-1]] + 1, side="left") - 1   # index of the first hit at or after off[e]
+    want_first = np.where(any_hit, pos - off[:-1], -1)
+    assert (first == want_first).all()
+    sub = slice(0, 300000)
+    assert (flags[sub] == hip.check_batch(q[sub], D.GH_CHECK_ENV | D.GH_PATH_FUSED)).all()
+
+
+def test_tiny_queue_capacity_forces_rechecks():
+    """GEAR_HIP_ITEM_CAP=64: nearly every sweep wave overflows its queue region, so nearly every
+    configuration is decided by the fused re-check inside the pipeline's last stage."""
+    w = W.metric_workload()
+    old = os.environ.get("GEAR_HIP_ITEM_CAP")
+    os.environ["GEAR_HIP_ITEM_CAP"] = "64"
+    try:
+        hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)   # the capacity is read at scene creation
+    finally:
+        if old is None:
+            del os.environ["GEAR_HIP_ITEM_CAP"]
+        else:
+            os.environ["GEAR_HIP_ITEM_CAP"] = old
+    q = w.configs(100000, seed=33, overshoot=0.01)
+    got = hip.check_batch(q, BOTH)
+    assert hip.pipeline_last_stats()["item_cap"] == 64
+    ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    assert (got == ref.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
