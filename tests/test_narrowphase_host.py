@@ -42,7 +42,7 @@ def rand_shape(rng, kind, spread):
 
 
 PAIRS = [("box", "box"), ("box", "ball"), ("ball", "box"), ("ball", "ball"), ("cyl", "box"), ("box", "cyl"),
-         ("cyl", "ball"), ("cyl", "cyl"), ("mesh", "box"), ("mesh", "mesh"), ("ball", "mesh")]
+         ("cyl", "ball"), ("ball", "cyl"), ("cyl", "cyl"), ("mesh", "box"), ("mesh", "mesh"), ("ball", "mesh")]
 
 
 @pytest.mark.parametrize("prec", [32, 64])
