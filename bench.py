@@ -73,13 +73,21 @@ def device_configs(w, n, seed, dtype, device):
     return ((hi_t - lo_t) * u + lo_t).to(dtype).contiguous()
 
 
-def cpu_baseline(w, precision, seconds=12.0):
+def cpu_baseline(w, precision, what, q_gpu=None, flags_gpu=None, seconds=12.0):
     """The reference's CPU path as restated by oracle/ ("port"): is_feasible-style early exits and the
     per-obstacle FK the reference does, (i) single-threaded (the reference is !Send) and (ii) one
-    independent chain per thread on the host cores available to this process."""
+    independent chain per thread on the host cores available to this process.  This leg is the only
+    place bench.py touches oracle/; while it is here it also checks the GPU's flags of the first timed
+    configurations (q_gpu, flags_gpu: host copies) against it."""
     from oracle import binding as orc
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, precision)
     dtype = np.float32 if precision == 32 else np.float64
+    parity = None
+    if q_gpu is not None:
+        from tests.parity import compare_flags
+        want, band = ora.check(q_gpu, what, threads=16)
+        rep = compare_flags(flags_gpu, want, band, precision)
+        parity = {kk: rep[kk] for kk in ("total", "mismatched", "in_band", "oracle_uncertified", "outside")}
     probe = w.configs(32, seed=999, dtype=dtype)
     t0 = time.perf_counter()
     ora.check(probe, faithful=True, redundant_fk=True, threads=1, want_band=False)
@@ -96,7 +104,7 @@ def cpu_baseline(w, precision, seconds=12.0):
     ora.check(qm, faithful=True, redundant_fk=True, threads=cores, want_band=False)
     multi = nm / (time.perf_counter() - t0)
     return {"value": multi, "unit": "configs/s", "cores": cores, "kind": "port",
-            "single_thread_value": single,
+            "single_thread_value": single, "gpu_parity_spot_check": parity,
             "sample": f"{nm} configs on {cores} threads and {n1} configs on 1 thread of the same scene and "
                       f"input distribution; C++ restatement of gear's path (oracle/), not the Rust crate"}
 
@@ -197,17 +205,6 @@ def main():
     total_configs = B * world * args.steps
     value = total_configs / elapsed
 
-    parity = None
-    if rank == 0 and not args.no_parity:
-        # bounded parity spot-check of the timed inputs against the CPU oracle
-        from oracle import binding as orc
-        from tests.parity import compare_flags
-        ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, args.precision)
-        k = 256
-        want, band = ora.check(q[:k].cpu().numpy(), what, threads=16)
-        rep = compare_flags(flags[:k].cpu().numpy(), want, band, args.precision)
-        parity = {kk: rep[kk] for kk in ("total", "mismatched", "in_band", "oracle_uncertified", "outside")}
-
     if rank == 0:
         achieved_tflops = flops_per_config * B / (kernel_ms * 1e-3) / 1e12
         peak = VALU_PEAK_TFLOPS[args.precision]
@@ -247,10 +244,11 @@ def main():
                         "design.  kernel_ms = HIP events on the launch stream around one step (all kernels of the step)"},
             "flag_rates": {"env": stats[0].item() / (B * world), "self": stats[1].item() / (B * world),
                            "limit": stats[2].item() / (B * world)},
-            "parity_spot_check": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.precision)
+            k = 0 if args.no_parity else 256
+            out["cpu_baseline"] = cpu_baseline(w, args.precision, what, q[:k].cpu().numpy() if k else None,
+                                               flags[:k].cpu().numpy() if k else None)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
