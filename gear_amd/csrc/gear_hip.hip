@@ -77,7 +77,7 @@ struct gh_scene {
   DevBuf q, flags, out, edges, store, first;
   // pipeline workspace (gear_pipeline.hpp): several sets, so that consecutive chunks of one call can be
   // in flight together (set 0 on the caller's stream, set k on aux[k])
-  struct PipeBufs { DevBuf hdr, items, hit, exact, pc, pstore; } pw[kMaxSets];
+  struct PipeBufs { DevBuf hdr, items, hit, exact, pc, pstore, stamps; } pw[kMaxSets];
   hipStream_t aux[kMaxSets] = {};  // aux[0] unused: set 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSets] = {};
   int last_sets = 0;  // workspace sets the last pipeline call used
@@ -298,6 +298,11 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     W.exact = (unsigned*)b.exact.p;
     W.pc = (PipeCounters*)b.pc.p;
     W.pstore = (T*)b.pstore.p;
+    static const bool want_stamps = getenv("GEAR_HIP_STAMPS") != nullptr;  // profiling aid
+    if (want_stamps) {
+      if ((rc = b.stamps.ensure(waves * 8 * sizeof(unsigned long long)))) return rc;
+      W.stamps = (unsigned long long*)b.stamps.p;
+    }
   }
   sc->last_sets = n_sets;
   void* gs = nullptr;
@@ -347,6 +352,22 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
       GH_HIP(hipEventRecord(sc->ev_join[k], sc->aux[k]));
       GH_HIP(hipStreamWaitEvent(st, sc->ev_join[k], 0));
     }
+  }
+  if (Ws[0].stamps) {  // profiling aid: mean cycles between k_narrow1's phase stamps, first workspace set
+    GH_HIP(hipStreamSynchronize(st));
+    const size_t nw = std::min(waves, (std::min(chunk, n) + kWave - 1) / kWave);
+    std::vector<unsigned long long> h(nw * 8);
+    GH_HIP(hipMemcpy(h.data(), Ws[0].stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    double d[8] = {0};
+    size_t cntd = 0;
+    for (size_t w = 0; w < nw; w++) {
+      if (h[w * 8 + 7] <= h[w * 8] || h[w * 8 + 2] == 0) continue;
+      for (int k = 1; k < 8; k++) d[k] += (double)(long long)(h[w * 8 + k] - h[w * 8 + k - 1]);
+      cntd++;
+    }
+    fprintf(stderr, "k_narrow1 stamps (mean cycles over %zu workgroups): hdr %.0f | codes %.0f | records %.0f | compute %.0f | barrier %.0f | rest+flush %.0f | tail %.0f\n",
+            cntd, d[1] / cntd, d[2] / cntd, d[3] / cntd, d[4] / cntd, d[5] / cntd, d[6] / cntd, d[7] / cntd);
+    GH_HIP(hipMemset(Ws[0].stamps, 0, h.size() * 8));
   }
   return GH_OK;
 }
@@ -465,7 +486,7 @@ void gh_scene_destroy(gh_scene* sc) {
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
     for (auto& b : sc->pw) {
       b.hdr.release(); b.items.release(); b.hit.release(); b.exact.release();
-      b.pc.release(); b.pstore.release();
+      b.pc.release(); b.pstore.release(); b.stamps.release();
     }
   }
   delete sc;

@@ -55,6 +55,7 @@ template <class T> struct PipeWs {
   unsigned* exact;       // [cap2]  wave << kItemBits | item
   PipeCounters* pc;
   T* pstore;             // [L][7][stride]  every shape pose (self pairs only)
+  unsigned long long* stamps;  // [waves][8] cycle stamps of k_narrow1's phases (GEAR_HIP_STAMPS=1, profiling), else null
   size_t stride;
   unsigned cap, cap2;
 };
@@ -515,6 +516,10 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   const Views<T> V(S);
   const int tid = threadIdx.x;
   const size_t wave = blockIdx.x;
+  auto stamp = [&](int k) {
+    if (W.stamps && tid == 0) W.stamps[wave * 8 + k] = (unsigned long long)clock64();
+  };
+  stamp(0);
   const WaveHdr h = W.hdr[wave];
   if (h.overflow) {  // the region ran full: the fused path re-checks these configurations
     const size_t cfg = wave * kWave + tid;
@@ -529,6 +534,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   LaneCounters lc{0, 0, 0, 0};
   bool redo = false;  // the exact queue ran full (uniform over the workgroup)
 
+  stamp(1);  // header in
   for (unsigned base = 0; base < h.count; base += kN1Threads) {
     const unsigned j = base + tid;
     bool valid = j < h.count;
@@ -542,10 +548,12 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     }
     if (what & 0x200u) valid = false;  // profiling ablation
     int r = PR_FREE;
+    if (base == 0) stamp(2);  // first round: codes in
     if (valid) {
       ShapeRef<T> A, B;
       Pose<T> wa, wb;
       item_fetch(S, V, W, wave, j, code, A, wa, B, wb, what);
+      if (base == 0 && W.stamps && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }  // records in
       r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
       if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
     }
@@ -559,7 +567,9 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       slot = __shfl(slot, (int)__builtin_ctzll(eb)) + lane_rank(eb);
       if (ex) exq[slot] = j;  // en <= kExLds - kN1Threads held before this round
     }
+    if (base == 0) stamp(4);  // first round computed
     __syncthreads();
+    if (base == 0) stamp(5);  // barrier passed
     if (en + kN1Threads > kExLds || base + kN1Threads >= h.count) {
       const unsigned cnt = en;
       if (cnt != 0) {
@@ -574,6 +584,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       }
     }
   }
+  stamp(6);  // all rounds and flushes done
   __syncthreads();
   if (tid < kWave) {
     const size_t cfg = wave * kWave + tid;
@@ -584,6 +595,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     if (redo) out |= kHitRedo;
     if (cfg < n) W.hit[cfg] = out;
   }
+  stamp(7);
 }
 
 // ---------------------------------------------------------------------------
