@@ -128,6 +128,7 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.sp_first_slot, &S.sp_first_slot))) return rc;
   if ((rc = upload(sc, H.sp_late_off, &S.sp_late_off))) return rc;
   if ((rc = upload(sc, H.sp_late, &S.sp_late))) return rc;
+  if ((rc = upload(sc, H.hot, &S.hot))) return rc;
   if ((rc = upload(sc, H.verts, &S.verts))) return rc;
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
   if ((rc = upload(sc, H.grids, &S.grids))) return rc;
@@ -341,7 +342,14 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
         default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
       }
     }
-    hipLaunchKernelGGL((k_narrow1<T>), dim3(grid_for(cnt)), dim3(kN1Threads), 0, cs, S, cnt, what, W);
+    {
+      // stage 1's shape data sits in LDS: the robot's always, the obstacles' when they fit 32 KB
+      const size_t rhot = (size_t)S.n_shapes * 4 * sizeof(T), ohot = (size_t)S.n_obs * 12 * sizeof(T);
+      if (rhot + ohot <= 32 * 1024)
+        hipLaunchKernelGGL((k_narrow1<T, true>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot + ohot, cs, S, cnt, what, W);
+      else
+        hipLaunchKernelGGL((k_narrow1<T, false>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot, cs, S, cnt, what, W);
+    }
     const unsigned g2 = (unsigned)std::min<size_t>(2048, (cnt + 255) / 256);
     hipLaunchKernelGGL((k_narrow2<T>), dim3(g2), dim3(256), 0, cs, S, what, W);
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
@@ -358,15 +366,18 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     const size_t nw = std::min(waves, (std::min(chunk, n) + kWave - 1) / kWave);
     std::vector<unsigned long long> h(nw * 8);
     GH_HIP(hipMemcpy(h.data(), Ws[0].stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    double d[8] = {0};
+    // stamps written: 0 start, 1 first trip in, 2 first round computed, 3 its barrier passed, 6 all rounds
+    // and flushes done, 7 end
+    const int at[6] = {0, 1, 2, 3, 6, 7};
+    double d[6] = {0};
     size_t cntd = 0;
     for (size_t w = 0; w < nw; w++) {
       if (h[w * 8 + 7] <= h[w * 8] || h[w * 8 + 2] == 0) continue;
-      for (int k = 1; k < 8; k++) d[k] += (double)(long long)(h[w * 8 + k] - h[w * 8 + k - 1]);
+      for (int k = 1; k < 6; k++) d[k] += (double)(long long)(h[w * 8 + at[k]] - h[w * 8 + at[k - 1]]);
       cntd++;
     }
-    fprintf(stderr, "k_narrow1 stamps (mean cycles over %zu workgroups): hdr %.0f | codes %.0f | records %.0f | compute %.0f | barrier %.0f | rest+flush %.0f | tail %.0f\n",
-            cntd, d[1] / cntd, d[2] / cntd, d[3] / cntd, d[4] / cntd, d[5] / cntd, d[6] / cntd, d[7] / cntd);
+    fprintf(stderr, "k_narrow1 stamps (mean cycles over %zu workgroups): first trip %.0f | round 1 %.0f | barrier %.0f | later rounds + flush %.0f | tail %.0f\n",
+            cntd, d[1] / cntd, d[2] / cntd, d[3] / cntd, d[4] / cntd, d[5] / cntd);
     GH_HIP(hipMemset(Ws[0].stamps, 0, h.size() * 8));
   }
   return GH_OK;

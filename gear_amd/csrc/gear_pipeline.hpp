@@ -31,7 +31,8 @@ constexpr int kExLds = 512;           // per-workgroup staging of exact entries 
 constexpr int kItemBits = 13;          // an exact entry packs (wave << kItemBits) | item index
 constexpr int kMaxItemCap = 1 << kItemBits;
 
-constexpr unsigned kSelfInline = 0xc0000000u;  // self item whose two poses are in its own and the next record
+// self item whose two poses are in its own and the next record: kSelfInline | s1 << 16 | s2 << 6 | lane (shapes < 1024)
+constexpr unsigned kSelfInline = 0xc0000000u;
 constexpr unsigned kItemSkip = 0xffffffffu;    // second record of such an item: not an item
 
 struct WaveHdr {
@@ -66,6 +67,13 @@ template <class T> struct PipeWs {
 // item has only its code (its two poses come from the pose store).
 template <class T> struct ItemIO;
 template <> struct ItemIO<float> {
+  struct Rec { uint4 a, b; };  // a record in registers
+  GD static Rec load(const float* rec) { const uint4* r = reinterpret_cast<const uint4*>(rec); return {r[0], r[1]}; }
+  GD static unsigned code(const Rec& r) { return r.a.x; }
+  GD static Pose<float> pose(const Rec& r) {
+    return {{__uint_as_float(r.a.y), __uint_as_float(r.a.z), __uint_as_float(r.a.w)},
+            {__uint_as_float(r.b.x), __uint_as_float(r.b.y), __uint_as_float(r.b.z), __uint_as_float(r.b.w)}};
+  }
   GD static void store(float* rec, unsigned code, const Pose<float>& p) {
     uint4* r = reinterpret_cast<uint4*>(rec);
     r[0] = make_uint4(code, __float_as_uint(p.t.x), __float_as_uint(p.t.y), __float_as_uint(p.t.z));
@@ -81,6 +89,10 @@ template <> struct ItemIO<float> {
   }
 };
 template <> struct ItemIO<double> {
+  struct Rec { double2 a, b, c, d; };
+  GD static Rec load(const double* rec) { const double2* r = reinterpret_cast<const double2*>(rec); return {r[0], r[1], r[2], r[3]}; }
+  GD static unsigned code(const Rec& r) { return (unsigned)__double_as_longlong(r.a.x); }
+  GD static Pose<double> pose(const Rec& r) { return {{r.a.y, r.b.x, r.b.y}, {r.c.x, r.c.y, r.d.x, r.d.y}}; }
   GD static void store(double* rec, unsigned code, const Pose<double>& p) {
     double2* r = reinterpret_cast<double2*>(rec);
     r[0] = make_double2(__longlong_as_double((long long)code), p.t.x);
@@ -398,7 +410,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
         } else if (hit) {
           const unsigned pos = count + 2u * lane_rank(hb);
           const bool s_first = s1 == s;  // s is the pair's first shape
-          ItemIO<T>::store(items + (size_t)pos * 8, kSelfInline | ((unsigned)p << 6) | (unsigned)lane, s_first ? ws : po);
+          ItemIO<T>::store(items + (size_t)pos * 8, kSelfInline | ((unsigned)s1 << 16) | ((unsigned)s2 << 6) | (unsigned)lane, s_first ? ws : po);
           ItemIO<T>::store(items + (size_t)(pos + 1) * 8, kItemSkip, s_first ? po : ws);
         }
         count += tot;
@@ -469,8 +481,7 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
                                            unsigned j, unsigned code, ShapeRef<T>& A, Pose<T>& wa, ShapeRef<T>& B,
                                            Pose<T>& wb, unsigned dbg = 0) {
   if ((code >> 30) == 3u) {
-    const int pi = (code >> 6) & 0xffffff;
-    const int s1 = V.spairs[4 * pi], s2 = V.spairs[4 * pi + 1];
+    const int s1 = (code >> 16) & 1023, s2 = (code >> 6) & 1023;
     const T* rec = W.items + (wave * (size_t)W.cap + j) * 8;
     A = shape_ref<T>(V.rshapes + s1);
     wa = ItemIO<T>::pose(rec);
@@ -501,18 +512,35 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
 
 // ---------------------------------------------------------------------------
 // k_narrow1: workgroup b (4 wavefronts) handles the items of sweep wave b, one item per lane.
-// Four waves per region, not one: an item is a chain of dependent loads (code -> shape records ->
-// poses) in front of ~700 VALU ops, and the rounds of one wave run back to back.
+//
+// The stage is a chain of memory round trips, each 1-2 us under load (cycle stamps, GEAR_HIP_STAMPS=1),
+// so everything that depends on nothing is requested at once when the workgroup starts: the wave
+// header, the item records of the first TWO rounds (code and pose together; indices clamped to the
+// region instead of waiting for the count), and the compact per-shape table of what stage 1 needs
+// (SceneDev::hot), which goes to LDS — the robot's part always, the obstacles' part when it fits
+// (OLDS).  After that one trip a round touches LDS only.  The poses of a self item are its own record
+// and the next one: the neighbour lane holds it (lane 63 re-reads it).
 // ---------------------------------------------------------------------------
 constexpr int kN1Threads = 256;
 
-template <class T>
+template <class T> GD ShapeRef<T> hot_ref(T hx, T hy, T hz, T kind) {
+  ShapeRef<T> r;
+  r.kind = (int)kind;
+  r.half = {hx, hy, hz};
+  r.br = T(0);
+  r.vb = r.vc = r.fb = r.fc = r.pn = 0;
+  return r;
+}
+
+template <class T, bool OLDS>
 __global__ void __launch_bounds__(kN1Threads)
 k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   __shared__ unsigned hits[4];      // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
   __shared__ unsigned exq[kExLds];  // staged exact entries
   __shared__ unsigned en;           // fill of exq
   __shared__ unsigned ebase;
+  using Rec = typename ItemIO<T>::Rec;
   const Views<T> V(S);
   const int tid = threadIdx.x;
   const size_t wave = blockIdx.x;
@@ -520,7 +548,17 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     if (W.stamps && tid == 0) W.stamps[wave * 8 + k] = (unsigned long long)clock64();
   };
   stamp(0);
+  T* hot = reinterpret_cast<T*>(gear_lds);  // [L][4], then (OLDS) [O][12]
+  const T* items = W.items + wave * 8 * (size_t)W.cap;
+  // ---- one trip: header, two rounds of records, the table ------------------------------------------
   const WaveHdr h = W.hdr[wave];
+  Rec rec[2];
+  rec[0] = ItemIO<T>::load(items + (size_t)min((unsigned)tid, W.cap - 1u) * 8);
+  rec[1] = ItemIO<T>::load(items + (size_t)min((unsigned)tid + kN1Threads, W.cap - 1u) * 8);
+  {
+    const int n_hot = S.n_shapes * 4 + (OLDS ? S.n_obs * 12 : 0);
+    for (int i = tid; i < n_hot; i += kN1Threads) hot[i] = S.hot[i];
+  }
   if (h.overflow) {  // the region ran full: the fused path re-checks these configurations
     const size_t cfg = wave * kWave + tid;
     if (tid < kWave && cfg < n) W.hit[cfg] = kHitRedo;
@@ -529,63 +567,94 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   if (tid < 4) hits[tid] = 0;
   if (tid == 4) en = 0;
   __syncthreads();
-  const T* items = W.items + wave * 8 * (size_t)W.cap;
+  stamp(1);  // header, records and table in
+  const T* ohot_g = S.hot + (size_t)S.n_shapes * 4;  // obstacle part in memory (!OLDS)
+  const T* ohot_l = hot + (size_t)S.n_shapes * 4;
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   bool redo = false;  // the exact queue ran full (uniform over the workgroup)
 
-  stamp(1);  // header in
-  for (unsigned base = 0; base < h.count; base += kN1Threads) {
-    const unsigned j = base + tid;
-    bool valid = j < h.count;
-    const unsigned code = valid ? ItemIO<T>::code(items + (size_t)j * 8) : 0u;
-    valid = valid && code != kItemSkip;
-    const int ln = code & 63;
-    const bool sf = (code >> 31) != 0;
-    if (valid) {
-      const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
-      valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
+  for (unsigned base = 0; base < h.count; base += 2 * kN1Threads) {
+    if (base != 0) {  // more than two rounds: rare
+      rec[0] = ItemIO<T>::load(items + (size_t)min(base + (unsigned)tid, W.cap - 1u) * 8);
+      rec[1] = ItemIO<T>::load(items + (size_t)min(base + (unsigned)tid + kN1Threads, W.cap - 1u) * 8);
     }
-    if (what & 0x200u) valid = false;  // profiling ablation
-    int r = PR_FREE;
-    if (base == 0) stamp(2);  // first round: codes in
-    if (valid) {
-      ShapeRef<T> A, B;
-      Pose<T> wa, wb;
-      item_fetch(S, V, W, wave, j, code, A, wa, B, wb, what);
-      if (base == 0 && W.stamps && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }  // records in
-      r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
-      if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
-    }
-    // stage the undecided items; when the staging area cannot take another full round, move it to
-    // the global exact queue with one atomic for the whole workgroup
-    const bool ex = r == PR_EXACT;
-    const unsigned long long eb = __ballot(ex);
-    unsigned slot = 0;
-    if (eb != 0) {
-      if ((tid & 63) == (int)__builtin_ctzll(eb)) slot = atomicAdd(&en, (unsigned)__popcll(eb));
-      slot = __shfl(slot, (int)__builtin_ctzll(eb)) + lane_rank(eb);
-      if (ex) exq[slot] = j;  // en <= kExLds - kN1Threads held before this round
-    }
-    if (base == 0) stamp(4);  // first round computed
-    __syncthreads();
-    if (base == 0) stamp(5);  // barrier passed
-    if (en + kN1Threads > kExLds || base + kN1Threads >= h.count) {
-      const unsigned cnt = en;
-      if (cnt != 0) {
-        if (tid == 0) ebase = atomicAdd(&W.pc->exact, cnt);
-        __syncthreads();
-        if (ebase + cnt > W.cap2) redo = true;
-        else
-          for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[ebase + k] = ((unsigned)wave << kItemBits) | exq[k];
-        __syncthreads();
-        if (tid == 0) en = 0;
-        __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const unsigned rbase = base + (unsigned)half * kN1Threads;
+      if (rbase >= h.count) break;  // uniform
+      const unsigned j = rbase + tid;
+      const Rec& rc = rec[half];
+      const unsigned code = ItemIO<T>::code(rc);
+      bool valid = j < h.count && code != kItemSkip;
+      const int ln = code & 63;
+      const bool sf = (code >> 31) != 0;
+      if (valid) {
+        const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
+        valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
+      }
+      if (what & 0x200u) valid = false;  // profiling ablation
+      // the next record's pose, for self items: the neighbour lane holds it
+      const Pose<T> mine = ItemIO<T>::pose(rc);
+      Pose<T> next;
+      next.t.x = __shfl_down(mine.t.x, 1); next.t.y = __shfl_down(mine.t.y, 1); next.t.z = __shfl_down(mine.t.z, 1);
+      next.r.i = __shfl_down(mine.r.i, 1); next.r.j = __shfl_down(mine.r.j, 1); next.r.k = __shfl_down(mine.r.k, 1);
+      next.r.w = __shfl_down(mine.r.w, 1);
+      int r = PR_FREE;
+      if (valid) {
+        ShapeRef<T> A, B;
+        Pose<T> wa, wb;
+        if ((code >> 30) == 3u) {  // self pair, both poses inline
+          const int s1 = (code >> 16) & 1023, s2 = (code >> 6) & 1023;
+          A = hot_ref(hot[4 * s1], hot[4 * s1 + 1], hot[4 * s1 + 2], hot[4 * s1 + 3]);
+          B = hot_ref(hot[4 * s2], hot[4 * s2 + 1], hot[4 * s2 + 2], hot[4 * s2 + 3]);
+          wa = mine;
+          wb = (tid & 63) == 63 ? ItemIO<T>::pose(items + (size_t)(j + 1) * 8) : next;
+        } else if (sf) {  // self pair of the brute-force sweep: poses in the pose store
+          item_fetch(S, V, W, wave, j, code, A, wa, B, wb, what);
+        } else {
+          const int s = (code >> 6) & 1023, o = (code >> 16) & 32767;
+          A = hot_ref(hot[4 * s], hot[4 * s + 1], hot[4 * s + 2], hot[4 * s + 3]);
+          wa = mine;
+          const T* ob = (OLDS ? ohot_l : ohot_g) + (size_t)o * 12;
+          B = hot_ref(ob[8], ob[9], ob[10], ob[3]);
+          wb = {{ob[0], ob[1], ob[2]}, {ob[4], ob[5], ob[6], ob[7]}};
+        }
+        r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
+        if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
+      }
+      if (rbase == 0) stamp(2);  // first round computed
+      // stage the undecided items; when the staging area cannot take another full round, move it to
+      // the global exact queue with one atomic for the whole workgroup
+      const bool ex = r == PR_EXACT;
+      const unsigned long long eb = __ballot(ex);
+      unsigned slot = 0;
+      if (eb != 0) {
+        if ((tid & 63) == (int)__builtin_ctzll(eb)) slot = atomicAdd(&en, (unsigned)__popcll(eb));
+        slot = __shfl(slot, (int)__builtin_ctzll(eb)) + lane_rank(eb);
+        if (ex) exq[slot] = j;  // en <= kExLds - kN1Threads held before this round
+      }
+      __syncthreads();
+      if (rbase == 0) stamp(3);  // barrier passed
+      const bool last = rbase + kN1Threads >= h.count;
+      if (en + kN1Threads > kExLds || last) {
+        const unsigned cnt = en;
+        if (cnt != 0) {
+          if (tid == 0) ebase = atomicAdd(&W.pc->exact, cnt);
+          __syncthreads();
+          if (ebase + cnt > W.cap2) redo = true;
+          else
+            for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[ebase + k] = ((unsigned)wave << kItemBits) | exq[k];
+          if (!last) {  // the staging area is used again
+            __syncthreads();
+            if (tid == 0) en = 0;
+            __syncthreads();
+          }
+        }
       }
     }
   }
   stamp(6);  // all rounds and flushes done
-  __syncthreads();
   if (tid < kWave) {
     const size_t cfg = wave * kWave + tid;
     const bool env_hit = ((hits[tid >> 5] >> (tid & 31)) & 1u) != 0;

@@ -36,6 +36,7 @@ struct HostTables {
   std::vector<int32_t> shape_grid;
   std::vector<uint32_t> cell_blk;  // [n_blocks][4], see SceneDev::cell_blk
   std::vector<int32_t> sp_first_slot, sp_late_off, sp_late;  // see SceneDev
+  std::vector<T> hot;                                        // see SceneDev::hot
   int n_first = 0;
   int n_slots = 0;
   T margin = 0;
@@ -462,6 +463,10 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
         H.spair_r.push_back(T(rr * (1.0 + 1e-4) + 1e-9));
       }
   }
+  for (const ShapeDev<T>& r : H.rshapes) H.hot.insert(H.hot.end(), {r.half[0], r.half[1], r.half[2], T(r.kind)});
+  for (const ShapeDev<T>& o : H.oshapes)
+    H.hot.insert(H.hot.end(), {o.lt[0], o.lt[1], o.lt[2], T(o.kind), o.lq[0], o.lq[1], o.lq[2], o.lq[3],
+                               o.half[0], o.half[1], o.half[2], T(0)});
   // self shape pairs by their later shape (walk order = shape index order)
   {
     const size_t L = H.rshapes.size(), NP = H.spair_r.size();

@@ -105,6 +105,9 @@ struct SceneDev {
   const int32_t* sp_first_slot;  // [n_shapes] LDS pose slot of a shape that is the earlier one of some pair, else -1
   const int32_t* sp_late_off;    // [n_shapes + 1] CSR offsets into sp_late
   const int32_t* sp_late;        // [n_spairs] self shape pair indices
+  // what stage 1 of the narrow phase needs of a shape, compact: robot shapes {half[3], kind} (4 T each),
+  // then obstacle shapes {t[3], kind | q[4] | half[3], 0} (12 T each); kinds stored as T(kind)
+  const T* hot;                  // [n_shapes * 4 + n_obs * 12]
   const T* verts;   // [..][3]
   const T* planes;  // [..][4]
   // broadphase grids (n_grids == 0: none built)
