@@ -81,6 +81,7 @@ struct gh_scene {
   hipStream_t aux[kMaxSets] = {};  // aux[0] unused: set 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSets] = {};
   int last_sets = 0;  // workspace sets the last pipeline call used
+  unsigned last_cap2 = 0;
   unsigned item_cap = 1024;  // survivor items per sweep wave before the fused path takes the wave over
   CountersDev* counters = nullptr;
   size_t elem() const { return precision == 32 ? 4 : 8; }
@@ -286,11 +287,11 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     gh_scene::PipeBufs& b = sc->pw[k];
     W = PipeWs<T>{};
     W.cap = sc->item_cap;
-    W.cap2 = (unsigned)std::min<size_t>(chunk * 2, 0x7fffffffu);
+    W.cap2 = (unsigned)std::min<size_t>(std::max<size_t>(chunk * 4 / kSegs, 4096), 0x7fffffffu / kSegs);  // per segment
     W.stride = chunk;
     if ((rc = b.hdr.ensure(waves * sizeof(WaveHdr))) || (rc = b.items.ensure(waves * W.cap * 8 * sizeof(T))) ||
         (rc = b.hit.ensure(chunk * 4)) ||
-        (rc = b.exact.ensure((size_t)W.cap2 * 4)) || (rc = b.pc.ensure(sizeof(PipeCounters))) ||
+        (rc = b.exact.ensure((size_t)W.cap2 * kSegs * 4)) || (rc = b.pc.ensure(sizeof(PipeCounters))) ||
         (do_self && !use_grid && (rc = b.pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
       return rc;
     W.hdr = (WaveHdr*)b.hdr.p;
@@ -306,6 +307,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     }
   }
   sc->last_sets = n_sets;
+  sc->last_cap2 = Ws[0].cap2;
   void* gs = nullptr;
   size_t gstride = 0;
   if (plan.global) {
@@ -350,8 +352,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
       else
         hipLaunchKernelGGL((k_narrow1<T, false>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot, cs, S, cnt, what, W);
     }
-    const unsigned g2 = (unsigned)std::min<size_t>(2048, (cnt + 255) / 256);
-    hipLaunchKernelGGL((k_narrow2<T>), dim3(g2), dim3(256), 0, cs, S, what, W);
+    // 16 workgroups per segment measured best (each lane takes two or three items in turn)
+    static const size_t g2max = [] { const char* e = getenv("GEAR_HIP_N2_GRID"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)16; }();
+    const unsigned g2 = (unsigned)std::min<size_t>(g2max, std::max<size_t>(1, (cnt / kSegs + 255) / 256));
+    hipLaunchKernelGGL((k_narrow2<T>), dim3(g2, kSegs), dim3(256), 0, cs, S, what, W);
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());
   }
@@ -562,8 +566,10 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
     PipeCounters h;
     GH_HIP(hipMemcpy(&h, b.pc.p, sizeof(h), hipMemcpyDeviceToHost));
     out[0] += h.candidates;
-    out[1] += h.exact;
-    out[2] += h.overflow;
+    for (int sgm = 0; sgm < kSegs; sgm++) {
+      out[1] += h.seg[sgm][0];
+      out[2] += h.seg[sgm][0] > sc->last_cap2 ? 1 : 0;
+    }
   }
   out[3] = sc->item_cap;
   return GH_OK;

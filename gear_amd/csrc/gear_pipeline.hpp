@@ -42,9 +42,15 @@ struct WaveHdr {
   unsigned overflow;
 };
 
+constexpr int kSegs = 64;  // segments of the exact queue
+
 struct PipeCounters {
-  unsigned exact;     // entries in the exact queue
-  unsigned overflow;  // the exact queue ran full
+  // The exact queue is kSegs independent segments, each with its own fill counter in its own 128-byte
+  // line: k_narrow1's workgroups append with one atomic each, and a single counter for all of them
+  // serialised the kernel (0.1 ms per 1M configurations, measured).  Workgroup b uses segment b % kSegs.
+  unsigned seg[kSegs][32];  // [s][0] = fill of segment s
+  unsigned exact;     // unused
+  unsigned overflow;  // unused
   unsigned long long candidates;  // broadphase candidates tested (only with GH_COUNT_CANDIDATES in `what`)
 };
 
@@ -53,12 +59,12 @@ template <class T> struct PipeWs {
   WaveHdr* hdr;          // [waves]
   T* items;              // [waves][cap] records of 8 T: {code, world pose (t, q) of an env item's robot shape}
   unsigned* hit;         // [configs]
-  unsigned* exact;       // [cap2]  wave << kItemBits | item
+  unsigned* exact;       // [kSegs][cap2]  wave << kItemBits | item
   PipeCounters* pc;
   T* pstore;             // [L][7][stride]  every shape pose (self pairs only)
   unsigned long long* stamps;  // [waves][8] cycle stamps of k_narrow1's phases (GEAR_HIP_STAMPS=1, profiling), else null
   size_t stride;
-  unsigned cap, cap2;
+  unsigned cap, cap2;    // items per queue region; entries per exact-queue segment
 };
 
 // One survivor = one 8-element record (32 B in f32, 64 B in f64), written and read with 16-byte
@@ -640,11 +646,11 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       if (en + kN1Threads > kExLds || last) {
         const unsigned cnt = en;
         if (cnt != 0) {
-          if (tid == 0) ebase = atomicAdd(&W.pc->exact, cnt);
+          if (tid == 0) ebase = atomicAdd(&W.pc->seg[wave % kSegs][0], cnt);
           __syncthreads();
           if (ebase + cnt > W.cap2) redo = true;
           else
-            for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[ebase + k] = ((unsigned)wave << kItemBits) | exq[k];
+            for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[(wave % kSegs) * (size_t)W.cap2 + ebase + k] = ((unsigned)wave << kItemBits) | exq[k];
           if (!last) {  // the staging area is used again
             __syncthreads();
             if (tid == 0) en = 0;
@@ -668,18 +674,19 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
 }
 
 // ---------------------------------------------------------------------------
-// k_narrow2: the exact stage over the dense exact queue (grid-stride)
+// k_narrow2: the exact stage over the segments of the exact queue (grid row = segment, grid-stride inside)
 // ---------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(256)
 k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
   const Views<T> V(S);
-  const unsigned total = min(W.pc->exact, W.cap2);
+  const unsigned seg = blockIdx.y;  // one grid row per segment of the exact queue
+  const unsigned total = min(W.pc->seg[seg][0], W.cap2);
   const unsigned nthreads = gridDim.x * blockDim.x;
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads) {
-    const unsigned ent = W.exact[e];
+    const unsigned ent = W.exact[seg * (size_t)W.cap2 + e];
     const size_t wave = ent >> kItemBits;
     const unsigned j = ent & (unsigned)(kMaxItemCap - 1);
     const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
