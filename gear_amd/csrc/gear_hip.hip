@@ -345,9 +345,11 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
       }
     }
     {
-      // stage 1's shape data sits in LDS: the robot's always, the obstacles' when they fit 32 KB
+      // stage 1's compact shape table: the robot's part goes to LDS; the obstacles' part is gathered from
+      // memory (48-byte records) — staging it in LDS too (GEAR_HIP_N1_OLDS=1, <= 32 KB) measured 1-3 % slower
       const size_t rhot = (size_t)S.n_shapes * 4 * sizeof(T), ohot = (size_t)S.n_obs * 12 * sizeof(T);
-      if (rhot + ohot <= 32 * 1024)
+      static const bool olds = [] { const char* e = getenv("GEAR_HIP_N1_OLDS"); return e && atoi(e) == 1; }();
+      if (olds && rhot + ohot <= 32 * 1024)
         hipLaunchKernelGGL((k_narrow1<T, true>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot + ohot, cs, S, cnt, what, W);
       else
         hipLaunchKernelGGL((k_narrow1<T, false>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot, cs, S, cnt, what, W);

@@ -523,8 +523,8 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
 // so everything that depends on nothing is requested at once when the workgroup starts: the wave
 // header, the item records of the first TWO rounds (code and pose together; indices clamped to the
 // region instead of waiting for the count), and the compact per-shape table of what stage 1 needs
-// (SceneDev::hot), which goes to LDS — the robot's part always, the obstacles' part when it fits
-// (OLDS).  After that one trip a round touches LDS only.  The poses of a self item are its own record
+// (SceneDev::hot): the robot's part goes to LDS, the obstacles' part is gathered per item from its
+// 48-byte records (OLDS stages it in LDS as well; measured slightly slower).  The poses of a self item are its own record
 // and the next one: the neighbour lane holds it (lane 63 re-reads it).
 // ---------------------------------------------------------------------------
 constexpr int kN1Threads = 256;
