@@ -335,8 +335,16 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     hipStream_t cs = set ? sc->aux[set] : st;
     GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
     if (use_grid) {
+      // four wavefronts per workgroup; the cull table joins them in LDS when it is at most 16 KB
       static const size_t lds_pad = [] { const char* e = getenv("GEAR_HIP_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-      hipLaunchKernelGGL((k_sweep_grid<T>), dim3(grid_for(cnt)), dim3(kWave), slot_bytes + first_bytes + lds_pad, cs, S, qc, cnt, what, W);
+      static const bool clds_ok = [] { const char* e = getenv("GEAR_HIP_SWEEP_CLDS"); return !(e && atoi(e) == 0); }();  // tuning aid
+      const unsigned per_wave = (unsigned)((slot_bytes + first_bytes + lds_pad + 15) / 16 * 16);
+      const size_t table = ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16;
+      const dim3 sg_grid((unsigned)((grid_for(cnt) + kSgWaves - 1) / kSgWaves)), sg_block(kWave * kSgWaves);
+      if (clds_ok && do_env && table <= 16 * 1024)
+        hipLaunchKernelGGL((k_sweep_grid<T, true>), sg_grid, sg_block, table + (size_t)per_wave * kSgWaves, cs, S, qc, cnt, what, W, per_wave);
+      else
+        hipLaunchKernelGGL((k_sweep_grid<T, false>), sg_grid, sg_block, (size_t)per_wave * kSgWaves, cs, S, qc, cnt, what, W, per_wave);
     } else {
       switch (K) {
         case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;

@@ -349,23 +349,40 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
 // ---------------------------------------------------------------------------
 template <class T> struct alignas(16) Cull4 { T x, y, z, r; };
 
-template <class T>
-__global__ void __launch_bounds__(kWave)
-k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W) {
+constexpr int kSgWaves = 4;  // wavefronts per k_sweep_grid workgroup (they share the LDS copy of the cull table)
+
+// CLDS: the obstacles' cull records (16 bytes each) sit in LDS, one copy per workgroup: the eight
+// record fetches of a cell block then go through the LDS pipe instead of the texture-address path,
+// which is what this kernel queues on.
+template <class T, bool CLDS>
+__global__ void __launch_bounds__(kWave * kSgWaves)
+k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, unsigned per_wave_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
-  const int lane = threadIdx.x;
-  const size_t wave = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const size_t n_waves = (n + kWave - 1) / kWave;
+  const size_t wave_raw = (size_t)blockIdx.x * kSgWaves + wv;
+  const bool wave_live = wave_raw < n_waves;      // the last workgroup may hold idle wavefronts
+  const size_t wave = wave_live ? wave_raw : n_waves - 1;
   const size_t col = wave * kWave + lane;
-  const bool live = col < n;
-  const size_t i = live ? col : n - 1;
+  const bool live = wave_live && col < n;
+  const size_t i = col < n ? col : n - 1;
   const T* qrow = q + i * (size_t)S.n_cols;
-  const PoseStore<T> slots{reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)lane};
+  // LDS: [cull table (CLDS)] [per wavefront: branch-point pose slots, poses of "earlier" self-pair shapes]
+  const size_t table_bytes = CLDS ? ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16 : 0;
+  unsigned char* my_lds = gear_lds + table_bytes + (size_t)wv * per_wave_lds;
+  const PoseStore<T> slots{reinterpret_cast<T*>(my_lds), (size_t)kWave, (size_t)lane};
   // poses of the shapes that are the earlier one of a self pair: [n_first][7][64]
-  const PoseStore<T> first{reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T)), (size_t)kWave, (size_t)lane};
+  const PoseStore<T> first{reinterpret_cast<T*>(my_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T)), (size_t)kWave, (size_t)lane};
   const GEAR_CAS int32_t* sp_first_slot = to_cas(S.sp_first_slot);
   const GEAR_CAS int32_t* sp_late_off = to_cas(S.sp_late_off);
   const GEAR_CAS int32_t* sp_late = to_cas(S.sp_late);
+  if (CLDS) {
+    T* tab = reinterpret_cast<T*>(gear_lds);
+    for (int k = threadIdx.x; k < (S.n_obs + 1) * 4; k += kWave * kSgWaves) tab[k] = S.ocull[k];
+    __syncthreads();
+  }
 
   const bool ok = limits_ok(S, V, qrow);
   const bool do_env = (what & 1u) && S.n_obs > 0;
@@ -377,7 +394,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
   const GEAR_CAS GridDev<T>* grids = to_cas(S.grids);
   const GEAR_CAS int32_t* shape_grid = to_cas(S.shape_grid);
   const uint4* __restrict__ blocks = reinterpret_cast<const uint4*>(S.cell_blk);
-  const Cull4<T>* __restrict__ ocull = reinterpret_cast<const Cull4<T>*>(S.ocull);
+  const Cull4<T>* __restrict__ ocull = CLDS ? reinterpret_cast<const Cull4<T>*>(gear_lds) : reinterpret_cast<const Cull4<T>*>(S.ocull);
   const unsigned sentinel = (unsigned)S.n_obs;
 
   const int n_walk = (do_env || do_self) ? S.n_shapes : 0;
@@ -478,7 +495,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
   if (what & 0x8000u) atomicAdd(&W.pc->candidates, ncand);
 
   const unsigned long long bad = __ballot(live && !ok);
-  if (lane == 0) W.hdr[wave] = {count, (unsigned)bad, (unsigned)(bad >> 32), overflow ? 1u : 0u};
+  if (lane == 0 && wave_live) W.hdr[wave] = {count, (unsigned)bad, (unsigned)(bad >> 32), overflow ? 1u : 0u};
 }
 
 // fetch the two shapes and poses of an item of wave `wave`
