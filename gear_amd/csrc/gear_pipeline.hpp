@@ -477,11 +477,18 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
         if (count + tot > W.cap) {
           overflow = true;
         } else {
+          // one pass per hit of the busiest lane (two or three), not one per slot of the block (eight):
+          // fewer store instructions, each with more active lanes
           unsigned pos = count + off;
+          unsigned hh = h;
+          while (__ballot(hh != 0) != 0) {
+            if (hh != 0) {
+              const unsigned z = (unsigned)__builtin_ctz(hh);
+              hh &= hh - 1u;
+              unsigned idz = id[0];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            if ((h >> j) & 1u) {
-              ItemIO<T>::store(items + (size_t)pos * 8, (id[j] << 16) | code_base, ws);
+              for (int j = 1; j < 8; j++) idz = z == (unsigned)j ? id[j] : idz;
+              ItemIO<T>::store(items + (size_t)pos * 8, (idz << 16) | code_base, ws);
               pos++;
             }
           }
