@@ -341,7 +341,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
       const unsigned per_wave = (unsigned)((slot_bytes + first_bytes + lds_pad + 15) / 16 * 16);
       const size_t table = ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16;
       const dim3 sg_grid((unsigned)((grid_for(cnt) + kSgWaves - 1) / kSgWaves)), sg_block(kWave * kSgWaves);
-      if (clds_ok && do_env && table <= 16 * 1024)
+      // ... and does not cost a resident workgroup: registers allow 4 (f32) / 3 (f64) workgroups per CU
+      const size_t lds_cu = 160 * 1024, wg_plain = (size_t)per_wave * kSgWaves, reg_wgs = sizeof(T) == 4 ? 4 : 3;
+      const size_t wgs_plain = std::min(reg_wgs, lds_cu / std::max<size_t>(wg_plain, 1)), wgs_table = lds_cu / (wg_plain + table);
+      if (clds_ok && do_env && table <= 16 * 1024 && wgs_table >= wgs_plain)
         hipLaunchKernelGGL((k_sweep_grid<T, true>), sg_grid, sg_block, table + (size_t)per_wave * kSgWaves, cs, S, qc, cnt, what, W, per_wave);
       else
         hipLaunchKernelGGL((k_sweep_grid<T, false>), sg_grid, sg_block, (size_t)per_wave * kSgWaves, cs, S, qc, cnt, what, W, per_wave);
