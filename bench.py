@@ -168,13 +168,25 @@ def main():
     executed_flops = (mix["F_fk"] + 11.0 * cand_per_config + 220.0 * mix["sat_per_config"] + 600.0 * mix["exact_per_config"]
                       if cand_per_config is not None else None)
 
-    def step():
-        scene.check_batch_dev(q, flags, what, stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, flags)
+    # With N > 1 the gather of step k's flag bytes (RCCL, its own stream) overlaps the check of step k+1:
+    # two flag buffers, the collective asynchronous, waited for one step later and before the clock stops.
+    fbuf = [flags, torch.zeros_like(flags)] if world > 1 else [flags]
+    pending = None
 
-    for _ in range(args.warmup):
-        step()
+    def step(k):
+        nonlocal pending
+        f = fbuf[k % len(fbuf)]
+        scene.check_batch_dev(q, f, what, stream)
+        if world > 1:
+            if pending is not None:
+                pending.wait()
+            pending = dist.all_gather_into_tensor(gathered, f, async_op=True)
+
+    for k in range(args.warmup):
+        step(k)
+    if pending is not None:
+        pending.wait()
+        pending = None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -182,11 +194,17 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        f = fbuf[k % len(fbuf)]
         ev[k][0].record()
-        scene.check_batch_dev(q, flags, what, stream)
+        scene.check_batch_dev(q, f, what, stream)
         ev[k][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, flags)
+            if pending is not None:
+                pending.wait()
+            pending = dist.all_gather_into_tensor(gathered, f, async_op=True)
+    if pending is not None:
+        pending.wait()
+        pending = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -196,6 +214,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    flags = fbuf[(args.steps - 1) % len(fbuf)]   # the buffer the last step wrote
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     # collision statistics (and a whole-job reduction when sharded)
@@ -218,7 +237,7 @@ def main():
                        "robot_shapes": int(w.robot_keep.desc.n_shapes), "obstacles": int(w.obstacle_keep.desc.n_shapes),
                        "self_pairs": int(w.robot_keep.desc.n_pairs), "margin": w.margin,
                        "batch_per_gpu": B, "checks": "env+self+limit", "sharding": f"dp{world}, scene replicated",
-                       "collectives": "all_gather(flags) per step" if world > 1 else "none"},
+                       "collectives": "all_gather(flags) per step, overlapped with the next step" if world > 1 else "none"},
             "roofline": {
                 "bound": "valu",
                 "kernel": ("k_sweep_grid + k_narrow1 + k_narrow2 + k_check(finalize), one launch of each per 1M-config chunk, "
