@@ -727,7 +727,8 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads) {
-    const unsigned ent = W.exact[seg * (size_t)W.cap2 + e];
+    unsigned ent = W.exact[seg * (size_t)W.cap2 + e];
+    if (what & 0x400000u) ent = __builtin_amdgcn_readfirstlane(ent);  // profiling ablation: one item per wave, no divergence
     const size_t wave = ent >> kItemBits;
     const unsigned j = ent & (unsigned)(kMaxItemCap - 1);
     const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);

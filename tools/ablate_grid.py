@@ -33,3 +33,4 @@ run(3 | PIPE | 0x60100, "env+self, no exact, wave-uniform obstacle + robot")
 run(3 | PIPE | 0x300, "env+self, no narrow (again)")
 run(3 | PIPE | 0x80300, "env+self, no narrow, no pose store")
 run(3 | PIPE, "env+self (again)")
+run(3 | PIPE | 0x400000, "env+self, exact stage without divergence (one item per wave)")
