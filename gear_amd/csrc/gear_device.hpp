@@ -165,6 +165,20 @@ template <class T> struct ShapeRef {
 
 template <class T> GD V3<T> sel(bool k, V3<T> x, V3<T> y) { return {k ? x.x : y.x, k ? x.y : y.y, k ? x.z : y.z}; }
 
+// ---- mesh tables ------------------------------------------------------------
+// Vertices and face planes are read either from the scene's flat pools (verts: 3 T per vertex, planes:
+// 4 T per face; any pointer type) or from a table of 4-wide, 16-byte aligned records (Vec4Tab: the
+// exact stage's LDS copy of SceneDev::mesh4), where one access brings a whole vertex or plane.
+template <class T> struct alignas(16) Quad { T x, y, z, w; };
+template <class T> struct Vec4Tab { const Quad<T>* p; };
+
+template <class T, class VP> GD V3<T> load_vert(VP verts, int i) { return {verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]}; }
+template <class T> GD V3<T> load_vert(Vec4Tab<T> t, int i) { const Quad<T> v = t.p[i]; return {v.x, v.y, v.z}; }
+template <class T, class PP> GD Quad<T> load_plane(PP planes, int i) {
+  return {planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]};
+}
+template <class T> GD Quad<T> load_plane(Vec4Tab<T> t, int i) { return t.p[i]; }
+
 // support point of the CORE shape (ball -> its centre) in shape-local direction d
 template <class T, class VP> GD V3<T> support_core(const ShapeRef<T>& s, VP verts, V3<T> d) {
   if (s.kind == SK_BOX) return {t_copysign(s.half.x, d.x), t_copysign(s.half.y, d.y), t_copysign(s.half.z, d.z)};
@@ -179,17 +193,15 @@ template <class T, class VP> GD V3<T> support_core(const ShapeRef<T>& s, VP vert
     k = k >= n ? k - n : k;
     const int km = k == 0 ? n - 1 : k - 1, kp = k == n - 1 ? 0 : k + 1;
     const int ring = s.vb + (d.z < T(0) ? 0 : n);
-    V3<T> p0{verts[3 * (ring + km)], verts[3 * (ring + km) + 1], verts[3 * (ring + km) + 2]};
-    V3<T> p1{verts[3 * (ring + k)], verts[3 * (ring + k) + 1], verts[3 * (ring + k) + 2]};
-    V3<T> p2{verts[3 * (ring + kp)], verts[3 * (ring + kp) + 1], verts[3 * (ring + kp) + 2]};
+    const V3<T> p0 = load_vert<T>(verts, ring + km), p1 = load_vert<T>(verts, ring + k), p2 = load_vert<T>(verts, ring + kp);
     const T d0 = dot(p0, d), d1 = dot(p1, d), d2 = dot(p2, d);
     V3<T> best = sel(d0 > d1, p0, p1);
     return sel(d2 > t_max(d0, d1), p2, best);
   }
-  V3<T> best{verts[3 * s.vb], verts[3 * s.vb + 1], verts[3 * s.vb + 2]};
+  V3<T> best = load_vert<T>(verts, s.vb);
   T bd = dot(best, d);
   for (int j = 1; j < s.vc; j++) {
-    V3<T> p{verts[3 * (s.vb + j)], verts[3 * (s.vb + j) + 1], verts[3 * (s.vb + j) + 2]};
+    const V3<T> p = load_vert<T>(verts, s.vb + j);
     T pd = dot(p, d);
     if (pd > bd) { bd = pd; best = p; }
   }
@@ -204,10 +216,14 @@ template <class T, class VP> GD V3<T> support_core(const ShapeRef<T>& s, VP vert
 template <class T> struct Simplex { V3<T> a, b, c, d; int n; };
 
 template <class T> GD void simplex_push(Simplex<T>& s, V3<T> w) {
-  if (s.n == 1) s.b = w;
-  else if (s.n == 2) s.c = w;
-  else s.d = w;
-  s.n++;
+  // value selects, not "if (n == 1) s.b = w; else ...": the compiler turns that chain into a store
+  // through a selected ADDRESS, which pins b, c, d in scratch memory (two memory round trips in every
+  // GJK iteration)
+  const int n = s.n;
+  s.b = sel(n == 1, w, s.b);
+  s.c = sel(n == 2, w, s.c);
+  s.d = sel(n >= 3, w, s.d);
+  s.n = n + 1;
 }
 // rebuild from the kept subset (3-bit mask) of (a, b, c)
 template <class T> GD void simplex_set(Simplex<T>& s, V3<T> a, V3<T> b, V3<T> c, int keep) {
@@ -394,15 +410,23 @@ GD bool inside_with_clearance(const ShapeRef<T>& P, const ShapeRef<T>& X, const 
   // by m + xr.  Most intersecting pairs fail it, and it needs no support evaluation.
   if (X.kind != SK_MESH || X.pn > 0) {
     const V3<T> cx = p_is_a ? rel.t : -rel_tmul(rel, rel.t);  // X's origin in P's frame
-    for (int f = 0; f < P.fc; f++) {
-      V3<T> n{planes[4 * (P.fb + f)], planes[4 * (P.fb + f) + 1], planes[4 * (P.fb + f) + 2]};
-      if (!(planes[4 * (P.fb + f) + 3] - dot(n, cx) - xr >= m)) return false;
+    // four faces at a time: their plane reads are in flight together (a face index past the end
+    // repeats the last face)
+    for (int f = 0; f < P.fc; f += 4) {
+      bool clear = true;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const Quad<T> pl = load_plane<T>(planes, P.fb + (f + j < P.fc ? f + j : P.fc - 1));
+        clear = clear && (pl.w - dot(V3<T>{pl.x, pl.y, pl.z}, cx) - xr >= m);
+      }
+      if (!clear) return false;
     }
     if (X.kind == SK_BALL) return true;  // a ball's core is its centre: the loop above was the whole test
   }
   for (int f = 0; f < P.fc; f++) {
-    V3<T> n{planes[4 * (P.fb + f)], planes[4 * (P.fb + f) + 1], planes[4 * (P.fb + f) + 2]};
-    T o = planes[4 * (P.fb + f) + 3];
+    const Quad<T> pl = load_plane<T>(planes, P.fb + f);
+    const V3<T> n{pl.x, pl.y, pl.z};
+    T o = pl.w;
     T h;
     if (p_is_a) {
       V3<T> px = rel_mul(rel, support_core(X, verts, rel_tmul(rel, n))) + rel.t;

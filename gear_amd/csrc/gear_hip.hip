@@ -132,6 +132,15 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.hot, &S.hot))) return rc;
   if ((rc = upload(sc, H.verts, &S.verts))) return rc;
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;
+  {
+    S.n_verts = (int)(H.verts.size() / 3);
+    S.n_planes = (int)(H.planes.size() / 4);
+    std::vector<T> m4((size_t)(S.n_verts + S.n_planes) * 4, T(0));
+    for (int v = 0; v < S.n_verts; v++)
+      for (int c = 0; c < 3; c++) m4[(size_t)4 * v + c] = H.verts[(size_t)3 * v + c];
+    std::copy(H.planes.begin(), H.planes.end(), m4.begin() + (size_t)4 * S.n_verts);
+    if ((rc = upload(sc, m4, &S.mesh4))) return rc;
+  }
   if ((rc = upload(sc, H.grids, &S.grids))) return rc;
   if ((rc = upload(sc, H.shape_grid, &S.shape_grid))) return rc;
   if ((rc = upload(sc, H.cell_blk, &S.cell_blk))) return rc;
@@ -262,7 +271,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
                  hipStream_t st) {
   // a wave's queue region holds item_cap survivors; keep the whole queue near 1 GiB and the wave index
   // inside the bits an exact entry leaves for it
-  const size_t max_waves = std::min<size_t>((size_t(1) << 30) / ((size_t)sc->item_cap * 8 * sizeof(T)), size_t(1) << (32 - kItemBits));
+  const size_t max_waves = std::min<size_t>((size_t(1) << 30) / ((size_t)sc->item_cap * 8 * sizeof(T)), (size_t)kMaxPipeWaves);
   size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, pipe_chunk(), std::max<size_t>(max_waves, 64) * kWave});
   // the fused kernel is the last stage (flag conversion + re-checks): it needs its own pose columns
   StorePlan plan = plan_store(sc, true);
@@ -368,7 +377,28 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     // 16 workgroups per segment measured best (each lane takes two or three items in turn)
     static const size_t g2max = [] { const char* e = getenv("GEAR_HIP_N2_GRID"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)16; }();
     const unsigned g2 = (unsigned)std::min<size_t>(g2max, std::max<size_t>(1, (cnt / kSegs + 255) / 256));
-    hipLaunchKernelGGL((k_narrow2<T>), dim3(g2, kSegs), dim3(256), 0, cs, S, what, W);
+    {
+      // the mesh pools (4-wide records) join the workgroup in LDS when they are at most 48 KB
+      const size_t mesh_bytes = (size_t)(S.n_verts + S.n_planes) * 4 * sizeof(T);
+      static const bool mlds_ok = [] { const char* e = getenv("GEAR_HIP_N2_MLDS"); return !(e && atoi(e) == 0); }();  // tuning aid
+      static const bool want_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;  // profiling aid
+      // entries a workgroup orders by class at a time (GEAR_HIP_N2_SLICE: 256 .. kN2Slice, tuning aid)
+      static const unsigned n2_slice = [] { const char* e = getenv("GEAR_HIP_N2_SLICE"); const int x = e ? atoi(e) : 256; return (unsigned)std::min(std::max(x, 256), kN2Slice) / 256u * 256u; }();
+      if (want_hist) {
+        hipLaunchKernelGGL((k_narrow2<T, false, true>), dim3(g2, kSegs), dim3(256), 0, cs, S, what, W, n2_slice);
+        GH_HIP(hipStreamSynchronize(cs));
+        PipeCounters h;
+        GH_HIP(hipMemcpy(&h, W.pc, sizeof(h), hipMemcpyDeviceToHost));
+        for (int r = 0; r < 2; r++) {
+          fprintf(stderr, r ? "k_narrow2 largest GJK iteration count per wavefront:" : "k_narrow2 GJK iterations per item:");
+          for (int k = 0; k < 48; k++) fprintf(stderr, " %u", h.hist[r][k]);
+          fprintf(stderr, "\n");
+        }
+      } else if (mlds_ok && mesh_bytes > 0 && mesh_bytes <= 48 * 1024)
+        hipLaunchKernelGGL((k_narrow2<T, true>), dim3(g2, kSegs), dim3(256), mesh_bytes, cs, S, what, W, n2_slice);
+      else
+        hipLaunchKernelGGL((k_narrow2<T, false>), dim3(g2, kSegs), dim3(256), 0, cs, S, what, W, n2_slice);
+    }
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());
   }

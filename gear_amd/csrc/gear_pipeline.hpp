@@ -28,8 +28,21 @@
 namespace gear_hip {
 
 constexpr int kExLds = 512;           // per-workgroup staging of exact entries in k_narrow1
-constexpr int kItemBits = 13;          // an exact entry packs (wave << kItemBits) | item index
+constexpr int kItemBits = 13;          // an exact entry packs class << (32 - kClassBits) | wave << kItemBits | item index
 constexpr int kMaxItemCap = 1 << kItemBits;
+constexpr int kClassBits = 4;          // pair class of an exact entry (exact_class); leaves 15 bits for the wave
+constexpr int kMaxPipeWaves = 1 << (32 - kItemBits - kClassBits);
+constexpr int kN2Slice = 1024;         // most entries a k_narrow2 workgroup orders by class at a time
+
+// Pair class of an undecided item: which support functions and which parts of the hollow-mesh rule its
+// exact query runs.  k_narrow2 orders its entries by class, so that the lanes of a wavefront take the
+// same branches (a wavefront of mixed items executes the union of all their paths).
+GD unsigned exact_class(int kind_a, int kind_b, bool self) {
+  // kinds: box 0, ball 1, mesh 2.  box-box 0, box-mesh 1, ball-mesh 2, mesh-box 3, mesh-ball 4, mesh-mesh 5
+  // (ball-ball and box-ball are decided in stage 1: 6); self pairs + 8
+  const unsigned long long lut = 0x543266160ull;
+  return (unsigned)((lut >> (4 * (kind_a * 3 + kind_b))) & 15u) + (self ? 8u : 0u);
+}
 
 // self item whose two poses are in its own and the next record: kSelfInline | s1 << 16 | s2 << 6 | lane (shapes < 1024)
 constexpr unsigned kSelfInline = 0xc0000000u;
@@ -52,6 +65,7 @@ struct PipeCounters {
   unsigned exact;     // unused
   unsigned overflow;  // unused
   unsigned long long candidates;  // broadphase candidates tested (only with GH_COUNT_CANDIDATES in `what`)
+  unsigned hist[2][48];  // GEAR_HIP_N2_HIST=1 (profiling): GJK iterations per exact item / the largest count in a wavefront
 };
 
 // layout of one launch chunk's workspace
@@ -584,8 +598,9 @@ __global__ void __launch_bounds__(kN1Threads)
 k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   __shared__ unsigned hits[4];      // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
-  __shared__ unsigned exq[kExLds];  // staged exact entries
-  __shared__ unsigned en;           // fill of exq
+  __shared__ unsigned exq[kExLds];  // staged exact entries: item | owner lane << kItemBits | self << (kItemBits + 6) | class << 28
+  __shared__ unsigned exq2[kExLds]; // the entries that are still undecided when the staging area is flushed
+  __shared__ unsigned en, en2;      // fill of exq, exq2
   __shared__ unsigned ebase;
   using Rec = typename ItemIO<T>::Rec;
   const Views<T> V(S);
@@ -612,7 +627,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     return;
   }
   if (tid < 4) hits[tid] = 0;
-  if (tid == 4) en = 0;
+  if (tid == 4) en = en2 = 0;
   __syncthreads();
   stamp(1);  // header, records and table in
   const T* ohot_g = S.hot + (size_t)S.n_shapes * 4;  // obstacle part in memory (!OLDS)
@@ -648,6 +663,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       next.r.i = __shfl_down(mine.r.i, 1); next.r.j = __shfl_down(mine.r.j, 1); next.r.k = __shfl_down(mine.r.k, 1);
       next.r.w = __shfl_down(mine.r.w, 1);
       int r = PR_FREE;
+      unsigned cls = 0;
       if (valid) {
         ShapeRef<T> A, B;
         Pose<T> wa, wb;
@@ -668,6 +684,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
           wb = {{ob[0], ob[1], ob[2]}, {ob[4], ob[5], ob[6], ob[7]}};
         }
         r = pair_stage1<T, false>(A, wa, B, wb, margin, lc);
+        cls = exact_class(A.kind, B.kind, sf);
         if (r == PR_HIT) atomicOr(&hits[(sf ? 2 : 0) + (ln >> 5)], 1u << (ln & 31));
       }
       if (rbase == 0) stamp(2);  // first round computed
@@ -679,7 +696,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       if (eb != 0) {
         if ((tid & 63) == (int)__builtin_ctzll(eb)) slot = atomicAdd(&en, (unsigned)__popcll(eb));
         slot = __shfl(slot, (int)__builtin_ctzll(eb)) + lane_rank(eb);
-        if (ex) exq[slot] = j;  // en <= kExLds - kN1Threads held before this round
+        if (ex) exq[slot] = j | ((unsigned)ln << kItemBits) | (sf ? 1u << (kItemBits + 6) : 0u) | (cls << (32 - kClassBits));  // en <= kExLds - kN1Threads held before this round
       }
       __syncthreads();
       if (rbase == 0) stamp(3);  // barrier passed
@@ -687,14 +704,35 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
       if (en + kN1Threads > kExLds || last) {
         const unsigned cnt = en;
         if (cnt != 0) {
-          if (tid == 0) ebase = atomicAdd(&W.pc->seg[wave % kSegs][0], cnt);
+          // Most undecided items belong to a configuration that some other item has meanwhile shown to
+          // collide (the metric scene: seven of eight): the flags are an OR, so those need no exact
+          // query.  Only the rest goes to the exact queue, which keeps k_narrow2's wavefronts full.
+#pragma unroll
+          for (int part = 0; part < kExLds / kN1Threads; part++) {
+            const unsigned k = (unsigned)(part * kN1Threads + tid);
+            const unsigned ent = exq[min(k, (unsigned)kExLds - 1u)];
+            const unsigned eln = (ent >> kItemBits) & 63u, esf = (ent >> (kItemBits + 6)) & 1u;
+            const bool keep = k < cnt && (((hits[2u * esf + (eln >> 5)] >> (eln & 31u)) & 1u) == 0 || (what & 0x1000000u));
+            const unsigned long long kb = __ballot(keep);
+            if (kb != 0) {
+              unsigned s2 = 0;
+              if ((tid & 63) == (int)__builtin_ctzll(kb)) s2 = atomicAdd(&en2, (unsigned)__popcll(kb));
+              s2 = __shfl(s2, (int)__builtin_ctzll(kb)) + lane_rank(kb);
+              if (keep) exq2[s2] = ent & ((unsigned)(kMaxItemCap - 1) | ~(0xffffffffu >> kClassBits));
+            }
+          }
           __syncthreads();
-          if (ebase + cnt > W.cap2) redo = true;
-          else
-            for (unsigned k = tid; k < cnt; k += kN1Threads) W.exact[(wave % kSegs) * (size_t)W.cap2 + ebase + k] = ((unsigned)wave << kItemBits) | exq[k];
-          if (!last) {  // the staging area is used again
+          const unsigned cnt2 = en2;
+          if (cnt2 != 0) {
+            if (tid == 0) ebase = atomicAdd(&W.pc->seg[wave % kSegs][0], cnt2);
             __syncthreads();
-            if (tid == 0) en = 0;
+            if (ebase + cnt2 > W.cap2) redo = true;
+            else
+              for (unsigned k = tid; k < cnt2; k += kN1Threads) W.exact[(wave % kSegs) * (size_t)W.cap2 + ebase + k] = ((unsigned)wave << kItemBits) | exq2[k];
+          }
+          if (!last) {  // the staging areas are used again
+            __syncthreads();
+            if (tid == 0) en = en2 = 0;
             __syncthreads();
           }
         }
@@ -715,31 +753,89 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
 }
 
 // ---------------------------------------------------------------------------
-// k_narrow2: the exact stage over the segments of the exact queue (grid row = segment, grid-stride inside)
+// k_narrow2: the exact stage over the segments of the exact queue (grid row = segment).
+//
+// A wavefront of 64 different items executes the union of their paths — every support function of both
+// shapes in every GJK iteration, both directions of the hollow-mesh rule — and with one or two waves per
+// SIMD nothing hides that.  So a workgroup takes a slice of up to `slice` entries, orders it by pair
+// class (counting sort in LDS; the class rides in the entry's top bits) and then works through it 256
+// entries at a time: most wavefronts hold one class and skip the other classes' code.
+// MLDS: the scene's mesh vertices and face planes sit in LDS as 16-byte records (SceneDev::mesh4), one
+// access per vertex or plane.
 // ---------------------------------------------------------------------------
-template <class T>
+template <class T, bool MLDS, bool HIST = false>
 __global__ void __launch_bounds__(256)
-k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
+k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned slice) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
+  __shared__ unsigned sorted[kN2Slice];
+  __shared__ unsigned bin[1 << kClassBits];
   const Views<T> V(S);
+  const int tid = threadIdx.x;
   const unsigned seg = blockIdx.y;  // one grid row per segment of the exact queue
   const unsigned total = min(W.pc->seg[seg][0], W.cap2);
-  const unsigned nthreads = gridDim.x * blockDim.x;
+  if (blockIdx.x * slice >= total) return;  // nothing for this workgroup (uniform)
+  const Vec4Tab<T> lverts{reinterpret_cast<const Quad<T>*>(gear_lds)};
+  const Vec4Tab<T> lplanes{reinterpret_cast<const Quad<T>*>(gear_lds) + S.n_verts};
+  if (MLDS) {
+    const Quad<T>* src = reinterpret_cast<const Quad<T>*>(S.mesh4);
+    Quad<T>* dst = reinterpret_cast<Quad<T>*>(gear_lds);
+    for (int k = tid; k < S.n_verts + S.n_planes; k += 256) dst[k] = src[k];
+  }
   const T margin = S.margin;
+  const unsigned* queue = W.exact + seg * (size_t)W.cap2;
   LaneCounters lc{0, 0, 0, 0};
-  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads) {
-    unsigned ent = W.exact[seg * (size_t)W.cap2 + e];
-    if (what & 0x400000u) ent = __builtin_amdgcn_readfirstlane(ent);  // profiling ablation: one item per wave, no divergence
-    const size_t wave = ent >> kItemBits;
-    const unsigned j = ent & (unsigned)(kMaxItemCap - 1);
-    const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
-    const size_t cfg = wave * kWave + (code & 63u);
-    const unsigned bit = (code >> 31) ? 2u : 1u;
-    if (W.hit[cfg] & (bit | kHitRedo)) continue;
-    if (what & 0x100u) continue;  // profiling ablation
-    ShapeRef<T> A, B;
-    Pose<T> wa, wb;
-    item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
-    if (pair_stage2<T, false>(A, wa, B, wb, V.verts, V.planes, margin, lc)) atomicOr(&W.hit[cfg], bit);
+  for (unsigned s0 = blockIdx.x * slice; s0 < total; s0 += gridDim.x * slice) {  // uniform
+    const unsigned cnt = min(slice, total - s0);
+    // ---- counting sort of the slice by class ---------------------------------------------------
+    if (tid < (1 << kClassBits)) bin[tid] = 0;
+    __syncthreads();
+    unsigned ent[kN2Slice / 256], rank[kN2Slice / 256];
+#pragma unroll
+    for (int r = 0; r < kN2Slice / 256; r++) {
+      const unsigned k = (unsigned)(r * 256 + tid);
+      ent[r] = k < cnt ? queue[s0 + k] : 0u;
+      rank[r] = 0;
+      if (k < cnt) rank[r] = (what & 0x2000000u) ? k : atomicAdd(&bin[ent[r] >> (32 - kClassBits)], 1u);  // ablation bit: queue order
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned acc = 0;
+      for (int c = 0; c < (1 << kClassBits); c++) { const unsigned b = bin[c]; bin[c] = acc; acc += b; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kN2Slice / 256; r++) {
+      const unsigned k = (unsigned)(r * 256 + tid);
+      if (k < cnt) sorted[((what & 0x2000000u) ? 0u : bin[ent[r] >> (32 - kClassBits)]) + rank[r]] = ent[r];
+    }
+    __syncthreads();
+    // ---- one item per lane ------------------------------------------------------------------------
+    for (unsigned k = (unsigned)tid; k < cnt; k += 256) {
+      unsigned e = sorted[k];
+      if (what & 0x400000u) e = __builtin_amdgcn_readfirstlane(e);  // profiling ablation: one item per wave, no divergence
+      const size_t wave = (e >> kItemBits) & (unsigned)(kMaxPipeWaves - 1);
+      const unsigned j = e & (unsigned)(kMaxItemCap - 1);
+      const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
+      const size_t cfg = wave * kWave + (code & 63u);
+      const unsigned bit = (code >> 31) ? 2u : 1u;
+      if (W.hit[cfg] & (bit | kHitRedo)) continue;
+      if (what & 0x100u) continue;  // profiling ablation
+      ShapeRef<T> A, B;
+      Pose<T> wa, wb;
+      item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
+      bool hit;
+      if (MLDS) hit = pair_stage2<T, HIST>(A, wa, B, wb, lverts, lplanes, margin, lc);
+      else hit = pair_stage2<T, HIST>(A, wa, B, wb, V.verts, V.planes, margin, lc);
+      if (hit) atomicOr(&W.hit[cfg], bit);
+      if (HIST) {
+        atomicAdd(&W.pc->hist[0][min(lc.exact_iters, 47u)], 1u);
+        unsigned mx = lc.exact_iters;
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
+        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) atomicAdd(&W.pc->hist[1][min(mx, 47u)], 1u);
+        lc.exact_iters = 0;
+      }
+    }
+    __syncthreads();  // `sorted` and `bin` are reused by the next slice
   }
 }
 

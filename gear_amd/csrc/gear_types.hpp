@@ -119,6 +119,11 @@ struct SceneDev {
   // outside a grid read it); a grid's head blocks are contiguous from off_base, one per cell.
   const uint32_t* cell_blk;     // [n_blocks][4]
   int32_t n_grids, pad4;
+  // the mesh pools once more as 4-wide records, vertices {x,y,z,0} then face planes {nx,ny,nz,offset}:
+  // the exact stage (k_narrow2) copies this table to LDS when it fits, and reads a vertex or a plane
+  // with one 16-byte access
+  const T* mesh4;               // [(n_verts + n_planes)][4]
+  int32_t n_verts, n_planes;
 };
 
 }  // namespace gear_hip
