@@ -296,7 +296,11 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     gh_scene::PipeBufs& b = sc->pw[k];
     W = PipeWs<T>{};
     W.cap = sc->item_cap;
-    W.cap2 = (unsigned)std::min<size_t>(std::max<size_t>(chunk * 4 / kSegs, 4096), 0x7fffffffu / kSegs);  // per segment
+    // per segment: two entries per configuration of the chunk in every pair class (a segment that runs
+    // full sends its workgroup's configurations to the fused path; GEAR_HIP_EXACT_CAP: tests force that)
+    const char* cap2_e = getenv("GEAR_HIP_EXACT_CAP");  // read per call: a test sets it for one call
+    const size_t cap2_env = cap2_e ? (size_t)strtoull(cap2_e, nullptr, 0) : (size_t)0;
+    W.cap2 = (unsigned)(cap2_env ? cap2_env : std::min<size_t>(std::max<size_t>(chunk * 2 / kSubs, 1024), 0x7fffffffu / kSegs));
     W.stride = chunk;
     if ((rc = b.hdr.ensure(waves * sizeof(WaveHdr))) || (rc = b.items.ensure(waves * W.cap * 8 * sizeof(T))) ||
         (rc = b.hit.ensure(chunk * 4)) ||
@@ -374,18 +378,17 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
       else
         hipLaunchKernelGGL((k_narrow1<T, false>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot, cs, S, cnt, what, W);
     }
-    // 16 workgroups per segment measured best (each lane takes two or three items in turn)
-    static const size_t g2max = [] { const char* e = getenv("GEAR_HIP_N2_GRID"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)16; }();
-    const unsigned g2 = (unsigned)std::min<size_t>(g2max, std::max<size_t>(1, (cnt / kSegs + 255) / 256));
+    // one-wave workgroups, grid row = segment: enough columns for an eighth of an entry per configuration
+    // in one class (more: grid-stride); the workgroups of empty segments leave at once
+    static const size_t g2div = [] { const char* e = getenv("GEAR_HIP_N2_GRID_DIV"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)8; }();
+    const unsigned g2 = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, cnt / (g2div * kSubs * kN2Threads)));
     {
       // the mesh pools (4-wide records) join the workgroup in LDS when they are at most 48 KB
       const size_t mesh_bytes = (size_t)(S.n_verts + S.n_planes) * 4 * sizeof(T);
       static const bool mlds_ok = [] { const char* e = getenv("GEAR_HIP_N2_MLDS"); return !(e && atoi(e) == 0); }();  // tuning aid
       static const bool want_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;  // profiling aid
-      // entries a workgroup orders by class at a time (GEAR_HIP_N2_SLICE: 256 .. kN2Slice, tuning aid)
-      static const unsigned n2_slice = [] { const char* e = getenv("GEAR_HIP_N2_SLICE"); const int x = e ? atoi(e) : 256; return (unsigned)std::min(std::max(x, 256), kN2Slice) / 256u * 256u; }();
       if (want_hist) {
-        hipLaunchKernelGGL((k_narrow2<T, false, true>), dim3(g2, kSegs), dim3(256), 0, cs, S, what, W, n2_slice);
+        hipLaunchKernelGGL((k_narrow2<T, false, true>), dim3(g2, kSegs), dim3(kN2Threads), 0, cs, S, what, W);
         GH_HIP(hipStreamSynchronize(cs));
         PipeCounters h;
         GH_HIP(hipMemcpy(&h, W.pc, sizeof(h), hipMemcpyDeviceToHost));
@@ -395,9 +398,9 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
           fprintf(stderr, "\n");
         }
       } else if (mlds_ok && mesh_bytes > 0 && mesh_bytes <= 48 * 1024)
-        hipLaunchKernelGGL((k_narrow2<T, true>), dim3(g2, kSegs), dim3(256), mesh_bytes, cs, S, what, W, n2_slice);
+        hipLaunchKernelGGL((k_narrow2<T, true>), dim3(g2, kSegs), dim3(kN2Threads), mesh_bytes, cs, S, what, W);
       else
-        hipLaunchKernelGGL((k_narrow2<T, false>), dim3(g2, kSegs), dim3(256), 0, cs, S, what, W, n2_slice);
+        hipLaunchKernelGGL((k_narrow2<T, false>), dim3(g2, kSegs), dim3(kN2Threads), 0, cs, S, what, W);
     }
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());

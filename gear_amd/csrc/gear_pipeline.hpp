@@ -28,15 +28,17 @@
 namespace gear_hip {
 
 constexpr int kExLds = 512;           // per-workgroup staging of exact entries in k_narrow1
-constexpr int kItemBits = 13;          // an exact entry packs class << (32 - kClassBits) | wave << kItemBits | item index
+constexpr int kItemBits = 13;          // an exact entry packs wave << kItemBits | item index
 constexpr int kMaxItemCap = 1 << kItemBits;
-constexpr int kClassBits = 4;          // pair class of an exact entry (exact_class); leaves 15 bits for the wave
-constexpr int kMaxPipeWaves = 1 << (32 - kItemBits - kClassBits);
-constexpr int kN2Slice = 1024;         // most entries a k_narrow2 workgroup orders by class at a time
+constexpr int kMaxPipeWaves = 1 << (32 - kItemBits);
+constexpr int kClassBits = 4;          // pair classes of the exact stage (exact_class)
+constexpr int kClasses = 1 << kClassBits;
+constexpr int kSubs = 16;              // queue segments per class (k_narrow1 workgroup b appends to sub-segment b % kSubs)
 
 // Pair class of an undecided item: which support functions and which parts of the hollow-mesh rule its
-// exact query runs.  k_narrow2 orders its entries by class, so that the lanes of a wavefront take the
-// same branches (a wavefront of mixed items executes the union of all their paths).
+// exact query runs.  The exact queue keeps one set of segments per class, so the lanes of a k_narrow2
+// wavefront take the same branches (a wavefront of mixed items executes the union of all their paths,
+// and with one or two waves per SIMD nothing hides that).
 GD unsigned exact_class(int kind_a, int kind_b, bool self) {
   // kinds: box 0, ball 1, mesh 2.  box-box 0, box-mesh 1, ball-mesh 2, mesh-box 3, mesh-ball 4, mesh-mesh 5
   // (ball-ball and box-ball are decided in stage 1: 6); self pairs + 8
@@ -55,12 +57,12 @@ struct WaveHdr {
   unsigned overflow;
 };
 
-constexpr int kSegs = 64;  // segments of the exact queue
+constexpr int kSegs = kClasses * kSubs;  // segments of the exact queue: segment = class * kSubs + sub
 
 struct PipeCounters {
   // The exact queue is kSegs independent segments, each with its own fill counter in its own 128-byte
-  // line: k_narrow1's workgroups append with one atomic each, and a single counter for all of them
-  // serialised the kernel (0.1 ms per 1M configurations, measured).  Workgroup b uses segment b % kSegs.
+  // line: k_narrow1's workgroups append with one atomic per class they hold, all in one trip, and a
+  // single counter for all of them serialised the kernel (0.1 ms per 1M configurations, measured).
   unsigned seg[kSegs][32];  // [s][0] = fill of segment s
   unsigned exact;     // unused
   unsigned overflow;  // unused
@@ -599,9 +601,10 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   __shared__ unsigned hits[4];      // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self bits
   __shared__ unsigned exq[kExLds];  // staged exact entries: item | owner lane << kItemBits | self << (kItemBits + 6) | class << 28
-  __shared__ unsigned exq2[kExLds]; // the entries that are still undecided when the staging area is flushed
-  __shared__ unsigned en, en2;      // fill of exq, exq2
-  __shared__ unsigned ebase;
+  __shared__ unsigned en;           // fill of exq
+  __shared__ unsigned cbin[kClasses];   // kept entries per class
+  __shared__ unsigned cbase[kClasses];  // where the class's entries go in its queue segment
+  __shared__ unsigned cfit[kClasses];   // how many of them the segment still takes
   using Rec = typename ItemIO<T>::Rec;
   const Views<T> V(S);
   const int tid = threadIdx.x;
@@ -627,14 +630,16 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
     return;
   }
   if (tid < 4) hits[tid] = 0;
-  if (tid == 4) en = en2 = 0;
+  if (tid == 4) en = 0;
+  if (tid >= 64 && tid < 64 + kClasses) cbin[tid - 64] = 0;
   __syncthreads();
   stamp(1);  // header, records and table in
   const T* ohot_g = S.hot + (size_t)S.n_shapes * 4;  // obstacle part in memory (!OLDS)
   const T* ohot_l = hot + (size_t)S.n_shapes * 4;
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
-  bool redo = false;  // the exact queue ran full (uniform over the workgroup)
+  __shared__ unsigned redo_l;  // a segment of the exact queue ran full
+  if (tid == 5) redo_l = 0;
 
   for (unsigned base = 0; base < h.count; base += 2 * kN1Threads) {
     if (base != 0) {  // more than two rounds: rare
@@ -707,38 +712,53 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
           // Most undecided items belong to a configuration that some other item has meanwhile shown to
           // collide (the metric scene: seven of eight): the flags are an OR, so those need no exact
           // query.  Only the rest goes to the exact queue, which keeps k_narrow2's wavefronts full.
+          // A kept entry takes its rank inside its class; then one atomic per class present, issued
+          // together by kClasses lanes (one trip), reserves the segments' slots.
+          unsigned e2[kExLds / kN1Threads], rk[kExLds / kN1Threads];
 #pragma unroll
           for (int part = 0; part < kExLds / kN1Threads; part++) {
             const unsigned k = (unsigned)(part * kN1Threads + tid);
             const unsigned ent = exq[min(k, (unsigned)kExLds - 1u)];
             const unsigned eln = (ent >> kItemBits) & 63u, esf = (ent >> (kItemBits + 6)) & 1u;
             const bool keep = k < cnt && (((hits[2u * esf + (eln >> 5)] >> (eln & 31u)) & 1u) == 0 || (what & 0x1000000u));
-            const unsigned long long kb = __ballot(keep);
-            if (kb != 0) {
-              unsigned s2 = 0;
-              if ((tid & 63) == (int)__builtin_ctzll(kb)) s2 = atomicAdd(&en2, (unsigned)__popcll(kb));
-              s2 = __shfl(s2, (int)__builtin_ctzll(kb)) + lane_rank(kb);
-              if (keep) exq2[s2] = ent & ((unsigned)(kMaxItemCap - 1) | ~(0xffffffffu >> kClassBits));
-            }
+            e2[part] = ent;
+            rk[part] = ~0u;
+            if (keep) rk[part] = atomicAdd(&cbin[ent >> (32 - kClassBits)], 1u);
           }
           __syncthreads();
-          const unsigned cnt2 = en2;
-          if (cnt2 != 0) {
-            if (tid == 0) ebase = atomicAdd(&W.pc->seg[wave % kSegs][0], cnt2);
-            __syncthreads();
-            if (ebase + cnt2 > W.cap2) redo = true;
-            else
-              for (unsigned k = tid; k < cnt2; k += kN1Threads) W.exact[(wave % kSegs) * (size_t)W.cap2 + ebase + k] = ((unsigned)wave << kItemBits) | exq2[k];
+          const unsigned sub = (unsigned)(wave % kSubs);
+          if (tid < kClasses) {
+            const unsigned c = cbin[tid];
+            // a segment that cannot take all c entries takes the ones that fit: every slot below
+            // min(fill, cap2) is then a written one, which is what k_narrow2 walks
+            unsigned b = 0, fit = 0;
+            if (c != 0) {
+              b = atomicAdd(&W.pc->seg[(unsigned)tid * kSubs + sub][0], c);
+              fit = b < W.cap2 ? min(c, W.cap2 - b) : 0u;
+              if (fit < c) redo_l = 1u;  // the fused path re-checks this wave's configurations
+            }
+            cbase[tid] = b;
+            cfit[tid] = fit;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int part = 0; part < kExLds / kN1Threads; part++) {
+            const unsigned cl = e2[part] >> (32 - kClassBits);
+            if (rk[part] < cfit[cl])  // not a kept entry: rank ~0u
+              W.exact[(cl * kSubs + sub) * (size_t)W.cap2 + cbase[cl] + rk[part]] = ((unsigned)wave << kItemBits) | (e2[part] & (unsigned)(kMaxItemCap - 1));
           }
           if (!last) {  // the staging areas are used again
             __syncthreads();
-            if (tid == 0) en = en2 = 0;
+            if (tid == 0) en = 0;
+            if (tid < kClasses) cbin[tid] = 0;
             __syncthreads();
           }
         }
       }
     }
   }
+  __syncthreads();
+  const bool redo = redo_l != 0;  // uniform over the workgroup
   stamp(6);  // all rounds and flushes done
   if (tid < kWave) {
     const size_t cfg = wave * kWave + tid;
@@ -753,89 +773,59 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
 }
 
 // ---------------------------------------------------------------------------
-// k_narrow2: the exact stage over the segments of the exact queue (grid row = segment).
-//
-// A wavefront of 64 different items executes the union of their paths — every support function of both
-// shapes in every GJK iteration, both directions of the hollow-mesh rule — and with one or two waves per
-// SIMD nothing hides that.  So a workgroup takes a slice of up to `slice` entries, orders it by pair
-// class (counting sort in LDS; the class rides in the entry's top bits) and then works through it 256
-// entries at a time: most wavefronts hold one class and skip the other classes' code.
+// k_narrow2: the exact stage over the segments of the exact queue (grid row = segment = one pair class,
+// grid-stride inside): the items of a wavefront run the same support functions and the same parts of the
+// hollow-mesh rule.  One wavefront per workgroup, so that the dispatcher spreads a short queue over
+// all SIMDs of the chip.
 // MLDS: the scene's mesh vertices and face planes sit in LDS as 16-byte records (SceneDev::mesh4), one
 // access per vertex or plane.
 // ---------------------------------------------------------------------------
+constexpr int kN2Threads = 64;
+
 template <class T, bool MLDS, bool HIST = false>
-__global__ void __launch_bounds__(256)
-k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned slice) {
+__global__ void __launch_bounds__(kN2Threads)
+k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
-  __shared__ unsigned sorted[kN2Slice];
-  __shared__ unsigned bin[1 << kClassBits];
   const Views<T> V(S);
   const int tid = threadIdx.x;
-  const unsigned seg = blockIdx.y;  // one grid row per segment of the exact queue
+  const unsigned seg = blockIdx.y;
   const unsigned total = min(W.pc->seg[seg][0], W.cap2);
-  if (blockIdx.x * slice >= total) return;  // nothing for this workgroup (uniform)
+  if (blockIdx.x * kN2Threads >= total) return;  // nothing for this workgroup (uniform)
   const Vec4Tab<T> lverts{reinterpret_cast<const Quad<T>*>(gear_lds)};
   const Vec4Tab<T> lplanes{reinterpret_cast<const Quad<T>*>(gear_lds) + S.n_verts};
   if (MLDS) {
     const Quad<T>* src = reinterpret_cast<const Quad<T>*>(S.mesh4);
     Quad<T>* dst = reinterpret_cast<Quad<T>*>(gear_lds);
-    for (int k = tid; k < S.n_verts + S.n_planes; k += 256) dst[k] = src[k];
+    for (int k = tid; k < S.n_verts + S.n_planes; k += kN2Threads) dst[k] = src[k];
+    __syncthreads();
   }
   const T margin = S.margin;
   const unsigned* queue = W.exact + seg * (size_t)W.cap2;
   LaneCounters lc{0, 0, 0, 0};
-  for (unsigned s0 = blockIdx.x * slice; s0 < total; s0 += gridDim.x * slice) {  // uniform
-    const unsigned cnt = min(slice, total - s0);
-    // ---- counting sort of the slice by class ---------------------------------------------------
-    if (tid < (1 << kClassBits)) bin[tid] = 0;
-    __syncthreads();
-    unsigned ent[kN2Slice / 256], rank[kN2Slice / 256];
-#pragma unroll
-    for (int r = 0; r < kN2Slice / 256; r++) {
-      const unsigned k = (unsigned)(r * 256 + tid);
-      ent[r] = k < cnt ? queue[s0 + k] : 0u;
-      rank[r] = 0;
-      if (k < cnt) rank[r] = (what & 0x2000000u) ? k : atomicAdd(&bin[ent[r] >> (32 - kClassBits)], 1u);  // ablation bit: queue order
+  for (unsigned k = blockIdx.x * kN2Threads + (unsigned)tid; k < total; k += gridDim.x * kN2Threads) {
+    unsigned e = queue[k];
+    if (what & 0x400000u) e = __builtin_amdgcn_readfirstlane(e);  // profiling ablation: one item per wave, no divergence
+    const size_t wave = e >> kItemBits;
+    const unsigned j = e & (unsigned)(kMaxItemCap - 1);
+    const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
+    const size_t cfg = wave * kWave + (code & 63u);
+    const unsigned bit = (code >> 31) ? 2u : 1u;
+    if (W.hit[cfg] & (bit | kHitRedo)) continue;
+    if (what & 0x100u) continue;  // profiling ablation
+    ShapeRef<T> A, B;
+    Pose<T> wa, wb;
+    item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
+    bool hit;
+    if (MLDS) hit = pair_stage2<T, HIST>(A, wa, B, wb, lverts, lplanes, margin, lc);
+    else hit = pair_stage2<T, HIST>(A, wa, B, wb, V.verts, V.planes, margin, lc);
+    if (hit) atomicOr(&W.hit[cfg], bit);
+    if (HIST) {
+      atomicAdd(&W.pc->hist[0][min(lc.exact_iters, 47u)], 1u);
+      unsigned mx = lc.exact_iters;
+      for (int d = 32; d > 0; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
+      if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) atomicAdd(&W.pc->hist[1][min(mx, 47u)], 1u);
+      lc.exact_iters = 0;
     }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned acc = 0;
-      for (int c = 0; c < (1 << kClassBits); c++) { const unsigned b = bin[c]; bin[c] = acc; acc += b; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kN2Slice / 256; r++) {
-      const unsigned k = (unsigned)(r * 256 + tid);
-      if (k < cnt) sorted[((what & 0x2000000u) ? 0u : bin[ent[r] >> (32 - kClassBits)]) + rank[r]] = ent[r];
-    }
-    __syncthreads();
-    // ---- one item per lane ------------------------------------------------------------------------
-    for (unsigned k = (unsigned)tid; k < cnt; k += 256) {
-      unsigned e = sorted[k];
-      if (what & 0x400000u) e = __builtin_amdgcn_readfirstlane(e);  // profiling ablation: one item per wave, no divergence
-      const size_t wave = (e >> kItemBits) & (unsigned)(kMaxPipeWaves - 1);
-      const unsigned j = e & (unsigned)(kMaxItemCap - 1);
-      const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
-      const size_t cfg = wave * kWave + (code & 63u);
-      const unsigned bit = (code >> 31) ? 2u : 1u;
-      if (W.hit[cfg] & (bit | kHitRedo)) continue;
-      if (what & 0x100u) continue;  // profiling ablation
-      ShapeRef<T> A, B;
-      Pose<T> wa, wb;
-      item_fetch(S, V, W, wave, j, code, A, wa, B, wb);
-      bool hit;
-      if (MLDS) hit = pair_stage2<T, HIST>(A, wa, B, wb, lverts, lplanes, margin, lc);
-      else hit = pair_stage2<T, HIST>(A, wa, B, wb, V.verts, V.planes, margin, lc);
-      if (hit) atomicOr(&W.hit[cfg], bit);
-      if (HIST) {
-        atomicAdd(&W.pc->hist[0][min(lc.exact_iters, 47u)], 1u);
-        unsigned mx = lc.exact_iters;
-        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d));
-        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) atomicAdd(&W.pc->hist[1][min(mx, 47u)], 1u);
-        lc.exact_iters = 0;
-      }
-    }
-    __syncthreads();  // `sorted` and `bin` are reused by the next slice
   }
 }
 

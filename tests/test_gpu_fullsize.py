@@ -101,3 +101,20 @@ def test_tiny_queue_capacity_forces_rechecks():
     assert hip.pipeline_last_stats()["item_cap"] == 64
     ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
     assert (got == ref.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
+
+
+def test_full_exact_queue_segments_are_rechecked():
+    """GEAR_HIP_EXACT_CAP=4: the segments of the exact queue (one set per pair class) run full almost at
+    once; the workgroups that could not append mark their configurations for the fused re-check."""
+    w = W.metric_workload()
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    q = w.configs(100000, seed=35, overshoot=0.01)
+    os.environ["GEAR_HIP_EXACT_CAP"] = "4"   # read per call
+    try:
+        got = hip.check_batch(q, BOTH)
+        st = hip.pipeline_last_stats()
+    finally:
+        del os.environ["GEAR_HIP_EXACT_CAP"]
+    assert st["exact_overflow"] > 0
+    assert (got == hip.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
+    assert (got == hip.check_batch(q, BOTH)).all()
