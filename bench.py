@@ -31,7 +31,7 @@ from gear_amd import workloads as W
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 PIPE_MIN = 1 << 14                          # gear_hip.hip kPipeMin: batches below it take the fused kernel alone
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "pipeline_traffic.json")   # tools/pmc_traffic.py
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "v8_pipeline_traffic.json")   # tools/pmc_traffic.py
 
 
 def measured_traffic(batch):
@@ -114,7 +114,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1 << 22, help="configurations per GPU per step")
+    ap.add_argument("--batch", type=int, default=1 << 23,
+                    help="configurations per GPU per step (8M: the per-GPU share of BASELINE configs[3]'s 64M batch on 8 GPUs)")
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,6 +229,7 @@ def main():
         achieved_tflops = flops_per_config * B / (kernel_ms * 1e-3) / 1e12
         peak = VALU_PEAK_TFLOPS[args.precision]
         bytes_per_config = w.dof * (4 if args.precision == 32 else 8) + 1
+        traffic = measured_traffic(B) if args.precision == 32 else None
         out = {
             "metric": "collision-checked configs/sec (whole node), 7-DOF arm vs 256 obstacles",
             "value": value, "unit": "configs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,8 +246,8 @@ def main():
                            "chunks rotating over 4 streams"
                            if B >= PIPE_MIN else "k_check (fused)"),
                 "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved_tflops / peak, "traffic": measured_traffic(B) if args.precision == 32 else None,
-                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r01/pipeline_traffic.json)",
+                "frac": achieved_tflops / peak, "traffic": traffic,
+                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r01/v8_pipeline_traffic.json)",
                 "algorithmic_bytes": bytes_per_config * B,
                 "kernel_ms": kernel_ms, "algorithmic_flops_per_config": flops_per_config, "mix": mix,
                 "executed": None if executed_flops is None else {
@@ -257,6 +259,8 @@ def main():
                             "decided, this entry how busy the vector units actually are"},
                 "hbm_algorithmic_GBps": bytes_per_config * B / (kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
+                "hbm_traffic_GBps": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
+                "hbm_traffic_frac_of_peak": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "sustained_fma_TFLOPs_measured": {"3_waves_per_simd": 111.9, "8_waves_per_simd": 129.9,
                                                   "source": "tools/valu_rate.hip, profiles/r01/valu_rate.txt"},
                 "note": "VALU-bound path (SURVEY 8d): the f32 vector peak equals the f32 MFMA peak; MFMA unused by "

@@ -21,8 +21,21 @@ def per_kernel(d, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+def configs_per_launch(d):
+    """One k_sweep_grid lane per configuration: its grid size is what one launch of every kernel covers.
+    (The round-1 v7 figure divided per-launch counters of 128k-configuration launches by the 512k of the
+    whole call and so understated the traffic four times: v7_pipeline_traffic_understated.json.)"""
+    f = glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv")[0]
+    g = {int(r["Grid_Size"]) for r in csv.DictReader(open(f)) if "k_sweep" in r["Kernel_Name"]}
+    return max(g) if g else None
+
+
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 n = int(sys.argv[3])
+seen = configs_per_launch(sys.argv[1])
+if seen and seen != n:
+    print(f"configs per launch: {n} given, the sweep's grid says {seen}: using {seen}", file=sys.stderr)
+    n = seen
 out = {"configs_per_launch": n, "unit": "bytes per configuration", "kernels": {}, "corrections":
        "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of coalesced reads), WRITE_SIZE KiB x 1024"}
 tot = 0.0
