@@ -245,7 +245,12 @@ size_t pipe_chunk() {  // GEAR_HIP_PIPE_CHUNK overrides (tuning aid)
   }();
   return v;
 }
-constexpr size_t kPipeMin = size_t(1) << 14;    // smaller batches take the fused kernel alone
+// Scenes with a broadphase grid take the pipeline at every batch size: an RRT line of a few hundred
+// samples is 55-70 us through its four small launches against ~100 us for the fused kernel, whose one
+// wavefront sweeps all L x O pairs and runs an exact stage of mixed pair classes.  Scenes without a grid
+// (fewer than 32 obstacles) keep the fused kernel below kPipeMin configurations.
+constexpr size_t kPipeMin = size_t(1) << 14;
+constexpr size_t kMultiStreamMin = size_t(3) << 20;  // batches from here on rotate their chunks over several streams
 constexpr uint32_t kForceFused = 0x1000u, kForcePipe = 0x2000u;  // `what` bits for tests and profiling
 constexpr uint32_t kNoGrid = 0x4000u;                             // pipeline without the broadphase grid
 
@@ -277,9 +282,11 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   StorePlan plan = plan_store(sc, true);
   // Consecutive chunks are independent.  With several workspace sets they rotate over the caller's
   // stream and the aux streams (fork / join through events), so that one chunk's narrow phase, which
-  // cannot fill the chip, overlaps the next chunk's sweep.  A batch that fits one chunk is split for that.
-  int n_sets = (!plan.global && n >= 4 * kPipeMin) ? pipe_streams() : 1;
-  if (n_sets > 1 && chunk * n_sets > n) chunk = ((n + n_sets - 1) / n_sets + kWave - 1) / kWave * kWave;
+  // cannot fill the chip, overlaps the next chunk's sweep.
+  // Forking onto the scene's streams and joining back costs ~0.1 ms per call whatever the size (measured:
+  // 128k configurations 105 us on one stream, 200 us on four; 1M 344 vs 452 us; 4M 1358 vs 1290 us), so
+  // only batches of at least kMultiStreamMin configurations and two chunks rotate over several streams.
+  int n_sets = (!plan.global && n >= kMultiStreamMin) ? pipe_streams() : 1;
   n_sets = (int)std::min<size_t>(n_sets, (n + chunk - 1) / chunk);
   const bool two = n_sets > 1;
   const size_t waves = chunk / kWave;
@@ -438,7 +445,8 @@ int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* fla
   const size_t slot_bytes = (size_t)sc->n_slots * 7 * kWave * sc->elem();
   const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 &&
                        slot_bytes + (size_t)(sc->max_shape_node + 1) * 2 * kWave * sc->elem() <= 32 * 1024;
-  if (pipe_ok && !(what & kForceFused) && (n >= kPipeMin || (what & kForcePipe))) {
+  const bool has_grid = (sc->precision == 32 ? sc->s32.n_grids : sc->s64.n_grids) > 0;
+  if (pipe_ok && !(what & kForceFused) && (n >= kPipeMin || has_grid || (what & kForcePipe))) {
     if (n == 0) return GH_OK;
     return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st)
                                : pipeline_dev<double>(sc, sc->s64, (const double*)q, n, what, flags, st);

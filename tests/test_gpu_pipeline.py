@@ -65,3 +65,20 @@ def test_pipeline_queue_overflow_is_rechecked():
     b = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE)
     c = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE | D.GH_PATH_NO_GRID)
     assert (a == b).all() and (a == c).all()
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_small_batches_default_path_equals_fused(prec):
+    """Scenes with a broadphase grid send every batch size through the pipeline (an RRT line is a few
+    hundred samples): tiny and ragged batch sizes must give the fused kernel's flags, in every mode."""
+    for w in (W.metric_workload(), W.pr2_workload(64)):
+        hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+        q = w.configs(5000, seed=77, dtype=hip.dtype, overshoot=0.02)
+        for n in (1, 2, 63, 64, 65, 300, 5000):
+            for what in (BOTH, D.GH_CHECK_ENV, D.GH_CHECK_SELF):
+                got = hip.check_batch(q[:n], what)
+                assert (got == hip.check_batch(q[:n], what | D.GH_PATH_FUSED)).all(), (w.name, n, what)
+        ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+        want, band = ora.check(q[:300], BOTH, threads=16)
+        rep = compare_flags(hip.check_batch(q[:300], BOTH), want, band, prec)
+        assert rep["outside"] == 0, rep
