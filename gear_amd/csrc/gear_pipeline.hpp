@@ -131,6 +131,13 @@ template <> struct ItemIO<double> {
   }
 };
 
+// The first workgroup of a chunk's sweep clears the exact queue's fill counters (k_narrow1, the next
+// kernel on the stream, is their first user): no separate memset launch per chunk.
+__device__ __forceinline__ void clear_segment_counters(PipeCounters* pc) {
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < kSegs; k += blockDim.x) pc->seg[k][0] = 0;
+}
+
 __device__ __forceinline__ unsigned lane_rank(unsigned long long b) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
 }
@@ -163,6 +170,7 @@ __global__ void __launch_bounds__(kWave)
 k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, int lds_centres, int max_node) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
+  clear_segment_counters(W.pc);
   const int lane = threadIdx.x;
   const size_t wave = blockIdx.x;
   const size_t col = wave * kWave + lane;
@@ -375,6 +383,7 @@ __global__ void __launch_bounds__(kWave * kSgWaves)
 k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, unsigned per_wave_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
+  clear_segment_counters(W.pc);
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const size_t n_waves = (n + kWave - 1) / kWave;
