@@ -354,7 +354,8 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     const PipeWs<T>& W = Ws[set];
     hipStream_t cs = set ? sc->aux[set] : st;
     // the sweep clears the queue counters itself; the diagnostic counters need the whole block cleared
-    if ((what & 0x8000u) || getenv("GEAR_HIP_N2_HIST")) GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
+    static const bool hist_env = getenv("GEAR_HIP_N2_HIST") != nullptr;
+    if ((what & 0x8000u) || hist_env) GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
     if (use_grid) {
       // four wavefronts per workgroup; the cull table joins them in LDS when it is at most 16 KB
       static const size_t lds_pad = [] { const char* e = getenv("GEAR_HIP_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
