@@ -527,9 +527,10 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
             if (hh != 0) {
               const unsigned z = (unsigned)__builtin_ctz(hh);
               hh &= hh - 1u;
-              unsigned idz = id[0];
-#pragma unroll
-              for (int j = 1; j < 8; j++) idz = z == (unsigned)j ? id[j] : idz;
+              // slot z of the block: 16 bits of one of its four words (a hit is never on a sentinel slot,
+              // so the raw words serve even in a chained block)
+              const unsigned wz = z < 4u ? (z < 2u ? w.x : w.y) : (z < 6u ? w.z : w.w);
+              const unsigned idz = (wz >> ((z & 1u) << 4)) & 0xffffu;
               ItemIO<T>::store(items + (size_t)pos * 8, (idz << 16) | code_base, ws);
               pos++;
             }
