@@ -30,7 +30,7 @@ from gear_amd import workloads as W
 
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-PIPE_MIN = 1 << 14                          # gear_hip.hip kPipeMin: batches below it take the fused kernel alone
+PIPE_MIN = 1 << 14                          # gear_hip.hip kPipeMin: scenes without a grid take the fused kernel below it
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "v8_pipeline_traffic.json")   # tools/pmc_traffic.py
 
 
@@ -243,8 +243,8 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "kernel": ("k_sweep_grid + k_narrow1 + k_narrow2 + k_check(finalize), one launch of each per 1M-config chunk, "
-                           "chunks rotating over 4 streams"
-                           if B >= PIPE_MIN else "k_check (fused)"),
+                           "chunks rotating over 4 streams from 3M configurations per call"
+                           if (B >= PIPE_MIN or int(w.obstacle_keep.desc.n_shapes) >= 32) else "k_check (fused)"),
                 "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak, "traffic": traffic,
                 "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r01/v8_pipeline_traffic.json)",

@@ -71,8 +71,9 @@ enum {
 enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2 };
 /* optional `what` bits that only choose HOW the batch is evaluated; the result
  * bytes are identical either way (tests/test_gpu_pipeline.py).  Without them
- * batches of >= 16384 configurations take the multi-kernel pipeline and
- * smaller ones the single fused kernel.  No counterpart in the reference. */
+ * a scene with a broadphase grid (>= 32 obstacles) takes the multi-kernel
+ * pipeline at every batch size; other scenes take it from 16384 configurations
+ * and the single fused kernel below.  No counterpart in the reference. */
 enum { GH_PATH_FUSED = 0x1000, GH_PATH_PIPELINE = 0x2000,
        GH_PATH_NO_GRID = 0x4000, /* pipeline: sweep every obstacle instead of the broadphase grid's cell lists */
        GH_COUNT_CANDIDATES = 0x8000 /* count the broadphase candidates (gh_pipeline_last_stats) */ };
