@@ -62,6 +62,34 @@ struct DevBuf {
 
 }  // namespace
 
+// Host memory that the device reads and writes in place (hipHostMalloc: pinned, coherent).  The small
+// synchronous calls of the host-buffer entry points (an RRT line, a start/goal check) stage their
+// arguments here and launch on it directly: no copy commands, one stream synchronisation.
+struct PinBuf {
+  void* p = nullptr;   // host address
+  void* d = nullptr;   // the same memory as the device addresses it
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return GH_OK;
+    release();
+    need = std::max<size_t>(need, 4096);
+    GH_HIP(hipHostMalloc(&p, need, hipHostMallocDefault));
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipHostFree(p); p = d = nullptr; return fail(GH_ERR_HIP, "hipHostGetDevicePointer failed"); }
+    bytes = need;
+    return GH_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = d = nullptr;
+    bytes = 0;
+  }
+};
+constexpr size_t kZeroCopyMax = 4096;  // configurations (and edges) up to which a host-buffer call runs in place
+bool zero_copy_ok() {  // GEAR_HIP_ZERO_COPY=0: always copy (measuring aid)
+  static const bool v = [] { const char* e = getenv("GEAR_HIP_ZERO_COPY"); return !(e && atoi(e) == 0); }();
+  return v;
+}
+
 constexpr int kMaxSets = 4;
 
 struct gh_scene {
@@ -75,6 +103,7 @@ struct gh_scene {
   hipStream_t stream = nullptr;
   std::mutex mu;
   DevBuf q, flags, out, edges, store, first;
+  PinBuf hq, hflags, hedges, hfirst;  // small host-buffer calls run on these in place
   // pipeline workspace (gear_pipeline.hpp): several sets, so that consecutive chunks of one call can be
   // in flight together (set 0 on the caller's stream, set k on aux[k])
   struct PipeBufs { DevBuf hdr, items, hit, exact, pc, pstore, stamps; } pw[kMaxSets];
@@ -447,7 +476,8 @@ int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* fla
   const size_t slot_bytes = (size_t)sc->n_slots * 7 * kWave * sc->elem();
   const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 &&
                        slot_bytes + (size_t)(sc->max_shape_node + 1) * 2 * kWave * sc->elem() <= 32 * 1024;
-  const bool has_grid = (sc->precision == 32 ? sc->s32.n_grids : sc->s64.n_grids) > 0;
+  static const bool small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;  // measuring aid: the pre-v8 rule
+  const bool has_grid = !small_fused && (sc->precision == 32 ? sc->s32.n_grids : sc->s64.n_grids) > 0;
   if (pipe_ok && !(what & kForceFused) && (n >= kPipeMin || has_grid || (what & kForcePipe))) {
     if (n == 0) return GH_OK;
     return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st)
@@ -550,6 +580,7 @@ void gh_scene_destroy(gh_scene* sc) {
     for (void* p : sc->tables) (void)hipFree(p);
     if (sc->counters) (void)hipFree(sc->counters);
     sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
+    sc->hq.release(); sc->hflags.release(); sc->hedges.release(); sc->hfirst.release();
     for (int k = 1; k < kMaxSets; k++) {
       if (sc->aux[k]) { (void)hipStreamSynchronize(sc->aux[k]); (void)hipStreamDestroy(sc->aux[k]); }
       if (sc->ev_join[k]) (void)hipEventDestroy(sc->ev_join[k]);
@@ -584,6 +615,14 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   int rc;
   size_t qb = n * sc->D * sc->elem();
+  if (n <= kZeroCopyMax && zero_copy_ok()) {
+    if ((rc = sc->hq.ensure(qb)) || (rc = sc->hflags.ensure(n))) return rc;
+    std::memcpy(sc->hq.p, q, qb);
+    if ((rc = check_dev(sc, sc->hq.d, n, what, (uint8_t*)sc->hflags.d, sc->stream, false))) return rc;
+    GH_HIP(hipStreamSynchronize(sc->stream));
+    std::memcpy(flags, sc->hflags.p, n);
+    return GH_OK;
+  }
   if ((rc = sc->q.ensure(qb)) || (rc = sc->flags.ensure(n))) return rc;
   GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
   if ((rc = check_dev(sc, sc->q.p, n, what, (uint8_t*)sc->flags.p, sc->stream, false))) return rc;
@@ -658,6 +697,24 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
   size_t n = edge_off[n_edges];
   if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
   int rc;
+  if (n <= kZeroCopyMax && n_edges <= kZeroCopyMax && zero_copy_ok()) {
+    Guard g(sc);  // held from staging to read-back: the staging buffers belong to the scene
+    if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+    const size_t qb = n * sc->D * sc->elem();
+    if ((rc = sc->hq.ensure(std::max<size_t>(qb, 1))) || (rc = sc->hflags.ensure(std::max<size_t>(n, 1))) ||
+        (rc = sc->hedges.ensure((n_edges + 1) * 4)) || (rc = sc->hfirst.ensure(n_edges * 4)))
+      return rc;
+    if (qb) std::memcpy(sc->hq.p, q, qb);
+    std::memcpy(sc->hedges.p, edge_off, (n_edges + 1) * 4);
+    if ((rc = check_dev(sc, sc->hq.d, n, what, (uint8_t*)sc->hflags.d, sc->stream, false))) return rc;
+    hipLaunchKernelGGL(k_edge_first, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, sc->stream,
+                       (const uint8_t*)sc->hflags.d, (const uint32_t*)sc->hedges.d, n_edges, bad_mask, (int32_t*)sc->hfirst.d);
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipStreamSynchronize(sc->stream));
+    if (n) std::memcpy(flags, sc->hflags.p, n);
+    std::memcpy(first_bad, sc->hfirst.p, n_edges * 4);
+    return GH_OK;
+  }
   {
     Guard g(sc);
     if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
