@@ -82,3 +82,26 @@ def test_small_batches_default_path_equals_fused(prec):
         want, band = ora.check(q[:300], BOTH, threads=16)
         rep = compare_flags(hip.check_batch(q[:300], BOTH), want, band, prec)
         assert rep["outside"] == 0, rep
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_in_place_host_calls_equal_copied_ones(prec):
+    """Host-buffer calls of <= 4096 configurations run in place on the scene's pinned staging buffers;
+    larger ones copy.  Both sides of the limit must give the same flags and first-bad indices."""
+    w = W.metric_workload()
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    q = w.configs(9000, seed=91, dtype=hip.dtype, overshoot=0.02)
+    ref = hip.check_batch(q, BOTH)                      # copied (9000 > 4096)
+    for n in (1, 100, 4095, 4096, 4097):
+        assert (hip.check_batch(q[:n], BOTH) == ref[:n]).all(), n
+    bad = D.GH_FLAG_ENV | D.GH_FLAG_LIMIT
+    for n, step in ((4096, 64), (4000, 37), (8192, 64)):
+        off = np.arange(0, n + 1, step, dtype=np.uint32)
+        if off[-1] != n:
+            off = np.append(off, np.uint32(n))
+        flags, first = hip.check_edges(q[:n], off, D.GH_CHECK_ENV, bad)
+        want = hip.check_batch(q[:n], D.GH_CHECK_ENV | D.GH_PATH_FUSED)
+        assert (flags == want).all(), n
+        for e in range(len(off) - 1):
+            seg = np.nonzero(want[off[e]:off[e + 1]] & bad)[0]
+            assert first[e] == (seg[0] if len(seg) else -1), (n, e)
