@@ -23,6 +23,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -951,13 +952,15 @@ template <class N> class JointPathPlanner {
   // not in the reference: where and how the batched engine runs
   int device = 0;
   bool speculate = true;            // hand whole lines, and several iterations / trials, to the GPU per call
-  size_t rrt_lookahead = 8;         // RRT iterations evaluated per GPU call when speculating
+  size_t rrt_lookahead = 4;         // RRT iterations evaluated per GPU call when speculating (4: 60 ms, 8: 64 ms, 2: 69 ms, 16: 78 ms per plan in the 96-obstacle field)
   size_t smoothing_lookahead = 16;  // smoothing trials evaluated per GPU call when speculating
   Rng rng{0};
   rrt::Stats stats;
 
   JointPathPlanner(Chain chain, CollisionChecker checker, N step, size_t max_try_, size_t num_smoothing_)
-      : collision_check_robot(std::move(chain)), collision_checker(std::move(checker)), step_length(step), max_try(max_try_), num_smoothing(num_smoothing_) {}
+      : collision_check_robot(std::move(chain)), collision_checker(std::move(checker)), step_length(step), max_try(max_try_), num_smoothing(num_smoothing_) {
+    if (const char* e = std::getenv("GEAR_HOST_RRT_LOOKAHEAD")) rrt_lookahead = (size_t)std::max(1, std::atoi(e));  // tuning aid
+  }
 
   std::vector<int> all_joints() const { return collision_check_robot.movable_nodes(); }
 
