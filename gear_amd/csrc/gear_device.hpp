@@ -315,9 +315,18 @@ template <class T> GD bool simplex_closest(Simplex<T>& s, V3<T>& v) {
   return true;
 }
 
+// GEAR_GJK_MAXIT: test builds of the host harness force the iteration cap with a tiny value
+// (tests/test_narrowphase_host.py); the product never defines it.
+#ifndef GEAR_GJK_MAXIT
+#define GEAR_GJK_MAXIT_F32 40
+#define GEAR_GJK_MAXIT_F64 64
+#else
+#define GEAR_GJK_MAXIT_F32 GEAR_GJK_MAXIT
+#define GEAR_GJK_MAXIT_F64 GEAR_GJK_MAXIT
+#endif
 template <class T> struct Tol;
-template <> struct Tol<float> { static constexpr float rel = 2e-6f; static constexpr int maxit = 40; };
-template <> struct Tol<double> { static constexpr double rel = 1e-13; static constexpr int maxit = 64; };
+template <> struct Tol<float> { static constexpr float rel = 2e-6f; static constexpr int maxit = GEAR_GJK_MAXIT_F32; };
+template <> struct Tol<double> { static constexpr double rel = 1e-13; static constexpr int maxit = GEAR_GJK_MAXIT_F64; };
 
 // GJK margin query between two convex cores in A's frame: true iff
 // dist(coreA, coreB) < m (m > 0).  CSO = A - B.
@@ -347,10 +356,15 @@ GD bool gjk_within(const ShapeRef<T>& A, const ShapeRef<T>& B, const Rel<T>& rel
     if (vv - vw <= Tol<T>::rel * vv) { iters = it; return false; }  // converged, |v| >= m
     simplex_push(s, w);
     if (!simplex_closest(s, v)) { iters = it; return true; }  // origin enclosed: intersecting
-    if (dot(v, v) >= vv) { iters = it; return false; }  // no progress: |v| is the distance
+    // No progress although neither bound decided: rounding stalled the descent with the margin still
+    // inside [v.w / |v|, |v|].  Undecided resolves to "within", the safe side for a collision checker;
+    // a stall happens a few ulps from convergence, i.e. deep inside the parity band.
+    if (dot(v, v) >= vv) { iters = it; return true; }
   }
+  // Iteration cap: ncollide's distance query turns GJK non-convergence into distance 0, which the
+  // reference's `dist < prediction` reads as colliding (oracle/gear_oracle.hpp gjk_distance).
   iters = it;
-  return false;
+  return true;
 }
 
 // ---- 15-axis separating-axis test with margin for two boxes ---------------

@@ -472,6 +472,9 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
 }
 
 int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted) {
+#ifndef GEAR_HIP_ABLATE
+  what &= kWhatPublic;  // undeclared bits never reach a kernel (the ablation build of tools/ keeps them)
+#endif
   if (!(sc->margin > 0)) what &= ~3u;  // distance >= 0 is never < a non-positive margin: only limits can fail
   const size_t slot_bytes = (size_t)sc->n_slots * 7 * kWave * sc->elem();
   const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 &&
@@ -670,13 +673,10 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
   return GH_OK;
 }
 
-int gh_check_edges_dev(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges, size_t n_samples,
-                       uint32_t what, uint8_t bad_mask, uint8_t* flags_dev, int32_t* first_bad_dev, void* stream) {
-  if (!sc || (n_edges && (!edge_off_dev || !first_bad_dev)) || (n_samples && (!q_dev || !flags_dev)))
-    return fail(GH_ERR_INVALID, "null argument");
-  Guard g(sc);
-  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
-  hipStream_t st = stream ? (hipStream_t)stream : sc->stream;
+// flags of every sample + first flagged sample per edge; the caller holds the scene's Guard
+static int check_edges_locked(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges,
+                              size_t n_samples, uint32_t what, uint8_t bad_mask, uint8_t* flags_dev,
+                              int32_t* first_bad_dev, hipStream_t st) {
   int rc = check_dev(sc, q_dev, n_samples, what, flags_dev, st, false);
   if (rc) return rc;
   if (n_edges) {
@@ -685,6 +685,16 @@ int gh_check_edges_dev(gh_scene* sc, const void* q_dev, const uint32_t* edge_off
     GH_HIP(hipGetLastError());
   }
   return GH_OK;
+}
+
+int gh_check_edges_dev(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges, size_t n_samples,
+                       uint32_t what, uint8_t bad_mask, uint8_t* flags_dev, int32_t* first_bad_dev, void* stream) {
+  if (!sc || (n_edges && (!edge_off_dev || !first_bad_dev)) || (n_samples && (!q_dev || !flags_dev)))
+    return fail(GH_ERR_INVALID, "null argument");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  return check_edges_locked(sc, q_dev, edge_off_dev, n_edges, n_samples, what, bad_mask, flags_dev, first_bad_dev,
+                            stream ? (hipStream_t)stream : sc->stream);
 }
 
 int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t n_edges, uint32_t what,
@@ -697,38 +707,33 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
   size_t n = edge_off[n_edges];
   if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
   int rc;
+  // ONE guard from staging to read-back on either path: the staging buffers, the workspace and the
+  // stream belong to the scene, and another host thread may be calling into the same scene
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  const size_t qb = n * sc->D * sc->elem();
   if (n <= kZeroCopyMax && n_edges <= kZeroCopyMax && zero_copy_ok()) {
-    Guard g(sc);  // held from staging to read-back: the staging buffers belong to the scene
-    if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
-    const size_t qb = n * sc->D * sc->elem();
     if ((rc = sc->hq.ensure(std::max<size_t>(qb, 1))) || (rc = sc->hflags.ensure(std::max<size_t>(n, 1))) ||
         (rc = sc->hedges.ensure((n_edges + 1) * 4)) || (rc = sc->hfirst.ensure(n_edges * 4)))
       return rc;
     if (qb) std::memcpy(sc->hq.p, q, qb);
     std::memcpy(sc->hedges.p, edge_off, (n_edges + 1) * 4);
-    if ((rc = check_dev(sc, sc->hq.d, n, what, (uint8_t*)sc->hflags.d, sc->stream, false))) return rc;
-    hipLaunchKernelGGL(k_edge_first, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, sc->stream,
-                       (const uint8_t*)sc->hflags.d, (const uint32_t*)sc->hedges.d, n_edges, bad_mask, (int32_t*)sc->hfirst.d);
-    GH_HIP(hipGetLastError());
+    if ((rc = check_edges_locked(sc, sc->hq.d, (const uint32_t*)sc->hedges.d, n_edges, n, what, bad_mask,
+                                 (uint8_t*)sc->hflags.d, (int32_t*)sc->hfirst.d, sc->stream)))
+      return rc;
     GH_HIP(hipStreamSynchronize(sc->stream));
     if (n) std::memcpy(flags, sc->hflags.p, n);
     std::memcpy(first_bad, sc->hfirst.p, n_edges * 4);
     return GH_OK;
   }
-  {
-    Guard g(sc);
-    if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
-    size_t qb = n * sc->D * sc->elem();
-    if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->flags.ensure(std::max<size_t>(n, 1))) ||
-        (rc = sc->edges.ensure((n_edges + 1) * 4)) || (rc = sc->first.ensure(n_edges * 4)))
-      return rc;
-    if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
-    GH_HIP(hipMemcpyAsync(sc->edges.p, edge_off, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
-  }
-  rc = gh_check_edges_dev(sc, sc->q.p, (const uint32_t*)sc->edges.p, n_edges, n, what, bad_mask, (uint8_t*)sc->flags.p,
-                          (int32_t*)sc->first.p, nullptr);
-  if (rc) return rc;
-  Guard g(sc);
+  if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->flags.ensure(std::max<size_t>(n, 1))) ||
+      (rc = sc->edges.ensure((n_edges + 1) * 4)) || (rc = sc->first.ensure(n_edges * 4)))
+    return rc;
+  if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
+  GH_HIP(hipMemcpyAsync(sc->edges.p, edge_off, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
+  if ((rc = check_edges_locked(sc, sc->q.p, (const uint32_t*)sc->edges.p, n_edges, n, what, bad_mask,
+                               (uint8_t*)sc->flags.p, (int32_t*)sc->first.p, sc->stream)))
+    return rc;
   if (n) GH_HIP(hipMemcpyAsync(flags, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
   GH_HIP(hipMemcpyAsync(first_bad, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
   GH_HIP(hipStreamSynchronize(sc->stream));
@@ -757,7 +762,7 @@ int gh_fk_batch(gh_scene* sc, const void* q, size_t n, void* poses) {
   return GH_OK;
 }
 
-int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint64_t* link_mask) {
+int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t* link_mask) {
   if (!sc || (n && (!q || !link_mask))) return fail(GH_ERR_INVALID, "null argument");
   if (n == 0 || sc->O == 0) return GH_OK;
   if (sc->N > 128) return fail(GH_ERR_TOO_LARGE, "gh_link_hits supports at most 128 nodes");
@@ -775,10 +780,10 @@ int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint64_t* link_mask) {
       unsigned long long* m = (unsigned long long*)sc->out.p + off * sc->O * W;
       if (sc->precision == 32)
         hipLaunchKernelGGL((k_link_hits<float>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s32,
-                           (const float*)sc->q.p + off * sc->D, cnt, m, W, (float*)gs, gstride);
+                           (const float*)sc->q.p + off * sc->D, cnt, what & kWhatPublic, m, W, (float*)gs, gstride);
       else
         hipLaunchKernelGGL((k_link_hits<double>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s64,
-                           (const double*)sc->q.p + off * sc->D, cnt, m, W, (double*)gs, gstride);
+                           (const double*)sc->q.p + off * sc->D, cnt, what & kWhatPublic, m, W, (double*)gs, gstride);
     });
     if (rc) return rc;
   }
@@ -787,7 +792,7 @@ int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint64_t* link_mask) {
   return GH_OK;
 }
 
-int gh_self_hits(gh_scene* sc, const void* q, size_t n, uint64_t* pair_mask) {
+int gh_self_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t* pair_mask) {
   if (!sc || (n && (!q || !pair_mask))) return fail(GH_ERR_INVALID, "null argument");
   if (n == 0 || sc->P == 0) return GH_OK;
   Guard g(sc);
@@ -804,10 +809,10 @@ int gh_self_hits(gh_scene* sc, const void* q, size_t n, uint64_t* pair_mask) {
       unsigned long long* m = (unsigned long long*)sc->out.p + off * W;
       if (sc->precision == 32)
         hipLaunchKernelGGL((k_self_hits<float>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s32,
-                           (const float*)sc->q.p + off * sc->D, cnt, m, W, (float*)gs, gstride);
+                           (const float*)sc->q.p + off * sc->D, cnt, what & kWhatPublic, m, W, (float*)gs, gstride);
       else
         hipLaunchKernelGGL((k_self_hits<double>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s64,
-                           (const double*)sc->q.p + off * sc->D, cnt, m, W, (double*)gs, gstride);
+                           (const double*)sc->q.p + off * sc->D, cnt, what & kWhatPublic, m, W, (double*)gs, gstride);
     });
     if (rc) return rc;
   }

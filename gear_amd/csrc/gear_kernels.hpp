@@ -28,6 +28,20 @@ template <class U> GD const GEAR_CAS U* to_cas(const U* p) {
 }
 
 constexpr int kWave = 64;
+
+// `what` bits a caller may pass (include/gear_hip.h): GH_CHECK_ENV | GH_CHECK_SELF | GH_CHECK_NO_LIMITS and
+// the GH_PATH_* / GH_COUNT_CANDIDATES evaluation hints.  Every extern "C" entry point masks `what` to
+// these, so a stray high bit can never change a result.
+constexpr uint32_t kWhatPublic = 0x3u | 0x10u | 0xf000u;
+constexpr uint32_t kWhatNoLimits = 0x10u;
+// Profiling ablations (skip a stage, force wave-uniform records, ...) give WRONG flags on purpose.  They
+// exist only in the -DGEAR_HIP_ABLATE build that tools/ablate_*.py load (gear_amd/build.py build_ablate);
+// in the product build the tests are compile-time false and the code behind them is dead.
+#ifdef GEAR_HIP_ABLATE
+#define GEAR_DBG(what, bits) (((what) & (bits)) != 0)
+#else
+#define GEAR_DBG(what, bits) false
+#endif
 constexpr unsigned kHitRedo = 0x80u;  // pipeline hit word, bit 7: re-check this configuration with the fused kernel
 
 template <class T> struct Views {
@@ -304,12 +318,12 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
 
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
-  const bool dbg_no_exact = (what & 0x100u) != 0, dbg_no_drain = (what & 0x200u) != 0;  // profiling ablations
+  const bool dbg_no_exact = GEAR_DBG(what, 0x100u), dbg_no_drain = GEAR_DBG(what, 0x200u);  // profiling ablations
   const T margin = S.margin;
   LaneCounters lc{0, 0, 0, 0};
   unsigned long long npairs = 0;
 
-  const bool ok = limits_ok(S, V, qrow);
+  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
 
   // ---- 1. FK walk -----------------------------------------------------------
   {
@@ -356,7 +370,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
         }
       }
       unsigned m[K];
-      if (what & 0x800u) {  // profiling ablation: no sweep
+      if (GEAR_DBG(what, 0x800u)) {  // profiling ablation: no sweep
 #pragma unroll
         for (int j = 0; j < K; j++) m[j] = 0u;
       } else {
@@ -392,7 +406,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
       unsigned m = mst[j * kWave + lane];
       const unsigned item_base = unit_base + ((unsigned)j << 6);
       if (is_env ? env_done : self_done) m = 0;
-      if (!push_ok || (what & 0x400u)) m = 0;  // 0x400: profiling ablation, no push
+      if (!push_ok || GEAR_DBG(what, 0x400u)) m = 0;  // 0x400: profiling ablation, no push
       if (COUNT) lc.cull_pass += __popc(m);
 
       const bool last_group = u == units - 1 && j == nsub - 1;
@@ -544,15 +558,15 @@ __device__ void walk_store_shapes(const SceneDev<T>& S, const Views<T>& V, const
 // ---------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(kWave)
-k_link_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, unsigned long long* __restrict__ masks, int W,
-            T* gstore, size_t gstride) {
+k_link_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, unsigned long long* __restrict__ masks,
+            int W, T* gstore, size_t gstride) {
   const Views<T> V(S);
   size_t i = (size_t)blockIdx.x * kWave + threadIdx.x;
   const bool live = i < n;
   if (!live) i = n - 1;
   const T* qrow = q + i * (size_t)S.n_cols;
   const PoseStore<T> st = make_store<T>(gstore, gstride, i);
-  const bool ok = limits_ok(S, V, qrow);
+  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
   walk_store_shapes(S, V, qrow, st);
   LaneCounters lc{0, 0, 0, 0};
   for (int o = 0; o < S.n_obs; o++) {
@@ -588,15 +602,15 @@ k_link_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, unsigned long long
 // ---------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(kWave)
-k_self_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, unsigned long long* __restrict__ masks, int W,
-            T* gstore, size_t gstride) {
+k_self_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, unsigned long long* __restrict__ masks,
+            int W, T* gstore, size_t gstride) {
   const Views<T> V(S);
   size_t i = (size_t)blockIdx.x * kWave + threadIdx.x;
   const bool live = i < n;
   if (!live) i = n - 1;
   const T* qrow = q + i * (size_t)S.n_cols;
   const PoseStore<T> st = make_store<T>(gstore, gstride, i);
-  const bool ok = limits_ok(S, V, qrow);
+  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
   walk_store_shapes(S, V, qrow, st);
   LaneCounters lc{0, 0, 0, 0};
   unsigned long long m = 0;

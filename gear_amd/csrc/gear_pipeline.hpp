@@ -183,11 +183,11 @@ k_sweep(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<
   T* sc = reinterpret_cast<T*>(gear_lds + (size_t)S.n_slots * 7 * kWave * sizeof(T)) + lane;  // [N][2][64]
   T* cen = sc - lane + (size_t)(max_node + 1) * 2 * kWave;  // [L][3][64] when lds_centres
 
-  const bool ok = limits_ok(S, V, qrow);
+  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
   const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
-  const bool dbg_no_sweep = (what & 0x800u) != 0, dbg_no_push = (what & 0x400u) != 0;  // profiling ablations
+  const bool dbg_no_sweep = GEAR_DBG(what, 0x800u), dbg_no_push = GEAR_DBG(what, 0x400u);  // profiling ablations
 
   T* items = W.items + wave * 8 * (size_t)W.cap;
   unsigned count = 0;  // wave-uniform
@@ -409,11 +409,11 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
     __syncthreads();
   }
 
-  const bool ok = limits_ok(S, V, qrow);
+  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
   const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
-  const bool dbg_no_sweep = (what & 0x800u) != 0;
+  const bool dbg_no_sweep = GEAR_DBG(what, 0x800u);
 
   T* items = W.items + wave * 8 * (size_t)W.cap;
   const GEAR_CAS GridDev<T>* grids = to_cas(S.grids);
@@ -502,7 +502,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
       // second cull: the obstacle's bounding sphere against the shape's ORIENTED box (a box's own extents,
       // a mesh's local bounding box, the cube around a ball).  Conservative like the first (the record's
       // radius carries margin and slack); it halves what is queued for the narrow phase.
-      if (!(what & 0x200000u) && __ballot(h != 0) != 0) {
+      if (!GEAR_DBG(what, 0x200000u) && __ballot(h != 0) != 0) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           if (__ballot((h >> j) & 1u) == 0) continue;  // uniform
@@ -573,9 +573,9 @@ __device__ __forceinline__ void item_fetch(const SceneDev<T>& S, const Views<T>&
   } else {
     int s = (code >> 6) & 1023;
     int o = (code >> 16) & 32767;
-    if (dbg & 0x10000u) o &= 3;  // profiling ablation: four distinct obstacle records (results are wrong)
-    if (dbg & 0x20000u) o = __builtin_amdgcn_readfirstlane(o);  // ablation: one obstacle record per wave, scalar loads
-    if (dbg & 0x40000u) s = __builtin_amdgcn_readfirstlane(s);  // ablation: one robot record per wave
+    if (GEAR_DBG(dbg, 0x10000u)) o &= 3;  // profiling ablation: four distinct obstacle records (results are wrong)
+    if (GEAR_DBG(dbg, 0x20000u)) o = __builtin_amdgcn_readfirstlane(o);  // ablation: one obstacle record per wave, scalar loads
+    if (GEAR_DBG(dbg, 0x40000u)) s = __builtin_amdgcn_readfirstlane(s);  // ablation: one robot record per wave
     A = shape_ref<T>(V.rshapes + s);
     wa = ItemIO<T>::pose(W.items + (wave * (size_t)W.cap + j) * 8);
     B = shape_ref<T>(V.oshapes + o);
@@ -670,7 +670,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
         const unsigned hw = hits[(sf ? 2 : 0) + (ln >> 5)];
         valid = ((hw >> (ln & 31)) & 1u) == 0;  // owner already known to collide
       }
-      if (what & 0x200u) valid = false;  // profiling ablation
+      if (GEAR_DBG(what, 0x200u)) valid = false;  // profiling ablation
       // the next record's pose, for self items: the neighbour lane holds it
       const Pose<T> mine = ItemIO<T>::pose(rc);
       Pose<T> next;
@@ -730,7 +730,7 @@ k_narrow1(SceneDev<T> S, size_t n, uint32_t what, PipeWs<T> W) {
             const unsigned k = (unsigned)(part * kN1Threads + tid);
             const unsigned ent = exq[min(k, (unsigned)kExLds - 1u)];
             const unsigned eln = (ent >> kItemBits) & 63u, esf = (ent >> (kItemBits + 6)) & 1u;
-            const bool keep = k < cnt && (((hits[2u * esf + (eln >> 5)] >> (eln & 31u)) & 1u) == 0 || (what & 0x1000000u));
+            const bool keep = k < cnt && (((hits[2u * esf + (eln >> 5)] >> (eln & 31u)) & 1u) == 0 || GEAR_DBG(what, 0x1000000u));
             e2[part] = ent;
             rk[part] = ~0u;
             if (keep) rk[part] = atomicAdd(&cbin[ent >> (32 - kClassBits)], 1u);
@@ -814,14 +814,14 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W) {
   LaneCounters lc{0, 0, 0, 0};
   for (unsigned k = blockIdx.x * kN2Threads + (unsigned)tid; k < total; k += gridDim.x * kN2Threads) {
     unsigned e = queue[k];
-    if (what & 0x400000u) e = __builtin_amdgcn_readfirstlane(e);  // profiling ablation: one item per wave, no divergence
+    if (GEAR_DBG(what, 0x400000u)) e = __builtin_amdgcn_readfirstlane(e);  // profiling ablation: one item per wave, no divergence
     const size_t wave = e >> kItemBits;
     const unsigned j = e & (unsigned)(kMaxItemCap - 1);
     const unsigned code = ItemIO<T>::code(W.items + (wave * (size_t)W.cap + j) * 8);
     const size_t cfg = wave * kWave + (code & 63u);
     const unsigned bit = (code >> 31) ? 2u : 1u;
     if (W.hit[cfg] & (bit | kHitRedo)) continue;
-    if (what & 0x100u) continue;  // profiling ablation
+    if (GEAR_DBG(what, 0x100u)) continue;  // profiling ablation
     ShapeRef<T> A, B;
     Pose<T> wa, wb;
     item_fetch(S, V, W, wave, j, code, A, wa, B, wb);

@@ -9,6 +9,7 @@ Flattening follows the reference's constructors:
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -18,6 +19,7 @@ from . import urdf as U
 GH_SHAPE_BOX, GH_SHAPE_BALL, GH_SHAPE_CYLINDER, GH_SHAPE_MESH = 0, 1, 2, 3
 GH_FLAG_ENV, GH_FLAG_SELF, GH_FLAG_LIMIT = 1, 2, 4
 GH_CHECK_ENV, GH_CHECK_SELF = 1, 2
+GH_CHECK_NO_LIMITS = 0x10
 GH_PATH_FUSED, GH_PATH_PIPELINE, GH_PATH_NO_GRID, GH_COUNT_CANDIDATES = 0x1000, 0x2000, 0x4000, 0x8000   # evaluation-path selection bits of `what` (same results)
 
 
@@ -151,10 +153,16 @@ class CollisionModel:
         return cls(m, prediction)
 
 
+_compound_ids = itertools.count(1)
+
+
 @dataclass
 class Compound:
-    """ncollide3d::shape::Compound<f64> as gear builds it: a flat list of posed shapes."""
+    """ncollide3d::shape::Compound<f64> as gear builds it: a flat list of posed shapes.
+    Treat it as immutable once built, as ncollide's is: `uid` (drawn at construction, never reused
+    by another object, unlike id()) is what the planner keys its GPU scene cache on."""
     shapes: List[ShapeSpec]
+    uid: int = field(default_factory=lambda: next(_compound_ids), compare=False)
 
     @classmethod
     def from_urdf_robot(cls, robot: U.UrdfRobot) -> "Compound":

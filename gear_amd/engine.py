@@ -49,8 +49,8 @@ def lib():
         L.gh_check_edges_dev.argtypes = [vp, vp, vp, sz, sz, u32, u8, vp, vp, vp]
         L.gh_fk_batch.argtypes = [vp, vp, sz, vp]
         L.gh_fk_batch_dev.argtypes = [vp, vp, sz, vp, vp]
-        L.gh_link_hits.argtypes = [vp, vp, sz, vp]
-        L.gh_self_hits.argtypes = [vp, vp, sz, vp]
+        L.gh_link_hits.argtypes = [vp, vp, sz, u32, vp]
+        L.gh_self_hits.argtypes = [vp, vp, sz, u32, vp]
         L.gh_check_batch_counted.argtypes = [vp, vp, sz, u32, vp, vp]
         L.gh_pipeline_last_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.gh_last_error.restype = C.c_char_p
@@ -127,18 +127,18 @@ class Scene:
         _check(lib().gh_fk_batch(self.h, _ptr(q), q.shape[0], _ptr(poses)))
         return poses
 
-    def link_hits(self, q) -> np.ndarray:
+    def link_hits(self, q, what=0) -> np.ndarray:
         q = self._q(q)
         W = lib().gh_link_mask_words(self.h)
         m = np.zeros((q.shape[0], self.n_obstacles, W), np.uint64)
-        _check(lib().gh_link_hits(self.h, _ptr(q), q.shape[0], _ptr(m)))
+        _check(lib().gh_link_hits(self.h, _ptr(q), q.shape[0], what, _ptr(m)))
         return m
 
-    def self_hits(self, q) -> np.ndarray:
+    def self_hits(self, q, what=0) -> np.ndarray:
         q = self._q(q)
         W = max((self.n_pairs + 63) // 64, 1)
         m = np.zeros((q.shape[0], W), np.uint64)
-        _check(lib().gh_self_hits(self.h, _ptr(q), q.shape[0], _ptr(m)))
+        _check(lib().gh_self_hits(self.h, _ptr(q), q.shape[0], what, _ptr(m)))
         return m
 
     # ---- device-buffer entry points (torch tensors on this scene's device) ----

@@ -22,6 +22,7 @@
 // through libgear_hip.so.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -497,15 +498,31 @@ struct CollisionChecker {
 };
 
 // ncollide3d Compound<f64> as gear builds it (collision_checker.rs:349-369): a flat list of posed shapes
-struct Compound {
-  std::vector<ShapeSpec> shapes;
+// Like ncollide's, a Compound is immutable once built (Compound::new(shapes) / shapes()): the planner
+// caches one GPU scene per compound, keyed on `id()`.  An id is drawn from a process-wide counter when the
+// shape list is set and travels with copies of that list, so equal ids always mean equal contents, and a
+// compound that is destroyed and rebuilt (even at the same address, with the same shape count) gets a new one.
+class Compound {
+ public:
+  Compound() : id_(next_id()) {}
+  explicit Compound(std::vector<ShapeSpec> shapes) : shapes_(std::move(shapes)), id_(next_id()) {}
+  const std::vector<ShapeSpec>& shapes() const { return shapes_; }
+  uint64_t id() const { return id_; }
   static Compound from_urdf_robot(const urdf::Robot& robot) {
-    Compound c;
+    std::vector<ShapeSpec> v;
     for (auto& l : robot.links)
-      for (auto& s : collision_specs(l, "")) c.shapes.push_back(s);
-    return c;
+      for (auto& s : collision_specs(l, "")) v.push_back(s);
+    return Compound(std::move(v));
   }
   static Compound from_urdf_file(const std::string& path) { return from_urdf_robot(urdf::read_file(path)); }
+
+ private:
+  static uint64_t next_id() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1, std::memory_order_relaxed);
+  }
+  std::vector<ShapeSpec> shapes_;
+  uint64_t id_;
 };
 
 // collision_checker.rs:314-329
@@ -621,7 +638,7 @@ class Scene {
       pair_names_.push_back(p);
     }
     if (objects)
-      for (auto& s : objects->shapes) oshapes.push_back(shape_desc(s, -1, omeshes));
+      for (auto& s : objects->shapes()) oshapes.push_back(shape_desc(s, -1, omeshes));
     std::vector<int32_t> cols(using_joints.begin(), using_joints.end());
     gh_robot_desc rd;
     std::memset(&rd, 0, sizeof(rd));
@@ -664,15 +681,15 @@ class Scene {
     int rc = gh_check_edges(h_, q, edge_off, n_edges, what, bad_mask, flags, first_bad);
     if (rc != GH_OK) throw gpu_error(rc);
   }
-  std::vector<uint64_t> link_hits(const void* q, size_t n) const {
+  std::vector<uint64_t> link_hits(const void* q, size_t n, uint32_t what = 0) const {
     std::vector<uint64_t> m(n * (size_t)n_obstacles_ * (size_t)gh_link_mask_words(h_));
-    int rc = gh_link_hits(h_, q, n, m.data());
+    int rc = gh_link_hits(h_, q, n, what, m.data());
     if (rc != GH_OK) throw gpu_error(rc);
     return m;
   }
-  std::vector<uint64_t> self_hits(const void* q, size_t n) const {
+  std::vector<uint64_t> self_hits(const void* q, size_t n, uint32_t what = 0) const {
     std::vector<uint64_t> m(n * std::max<size_t>((pair_names_.size() + 63) / 64, 1));
-    int rc = gh_self_hits(h_, q, n, m.data());
+    int rc = gh_self_hits(h_, q, n, what, m.data());
     if (rc != GH_OK) throw gpu_error(rc);
     return m;
   }
@@ -974,7 +991,8 @@ template <class N> class JointPathPlanner {
     auto u = all_joints();
     std::vector<N> q = current(u);
     uint8_t f = 0;
-    scene(u, &objects).check_batch(q.data(), 1, GH_CHECK_ENV, &f);
+    // no limit gate: the reference's has_any_colliding evaluates distances on whatever state the chain holds
+    scene(u, &objects).check_batch(q.data(), 1, GH_CHECK_ENV | GH_CHECK_NO_LIMITS, &f);
     return (f & GH_FLAG_ENV) != 0;
   }
   // :100-110 — obstacle-major, per obstacle in chain order, duplicates kept
@@ -982,7 +1000,7 @@ template <class N> class JointPathPlanner {
     auto u = all_joints();
     std::vector<N> q = current(u);
     Scene& sc = scene(u, &objects);
-    auto m = sc.link_hits(q.data(), 1);
+    auto m = sc.link_hits(q.data(), 1, GH_CHECK_NO_LIMITS);
     const int W = gh_link_mask_words(sc.handle());
     std::vector<std::string> names;
     for (int o = 0; o < sc.n_obstacles(); o++)
@@ -1000,7 +1018,7 @@ template <class N> class JointPathPlanner {
     auto u = all_joints();
     std::vector<N> q = current(u);
     uint8_t f = 0;
-    scene(u, nullptr).check_batch(q.data(), 1, GH_CHECK_SELF, &f);
+    scene(u, nullptr).check_batch(q.data(), 1, GH_CHECK_SELF | GH_CHECK_NO_LIMITS, &f);
     return (f & GH_FLAG_SELF) != 0;
   }
   // :130-134
@@ -1008,7 +1026,7 @@ template <class N> class JointPathPlanner {
     auto u = all_joints();
     std::vector<N> q = current(u);
     Scene& sc = scene(u, nullptr);
-    auto m = sc.self_hits(q.data(), 1);
+    auto m = sc.self_hits(q.data(), 1, GH_CHECK_NO_LIMITS);
     std::vector<std::pair<std::string, std::string>> out;
     for (size_t p = 0; p < sc.pair_names().size(); p++)
       if ((m[p >> 6] >> (p & 63)) & 1) out.push_back(sc.pair_names()[p]);
@@ -1085,7 +1103,7 @@ template <class N> class JointPathPlanner {
     std::ostringstream key;
     key.precision(17);
     for (int i : using_joints) key << i << ',';
-    key << '|' << (const void*)objects << '|' << (objects ? objects->shapes.size() : 0) << '|' << collision_checker.prediction << '|';
+    key << '|' << (objects ? objects->id() : 0) << '|' << collision_checker.prediction << '|';  // Compound::id: contents, not address
     for (size_t k = 0; k < driven.size(); k++)
       if (!driven[k]) key << collision_check_robot.nodes[k].position << ',';
     for (auto& p : self_collision_pairs) key << p.first << ':' << p.second << ',';

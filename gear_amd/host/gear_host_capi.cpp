@@ -142,22 +142,23 @@ int gp_compound_from_urdf_file(const char* path, gp_compound** out) {
 
 int gp_compound_from_shapes(const gh_shape_desc* shapes, int n, gp_compound** out) {
   return guarded([&]() -> int {
-    auto c = std::make_unique<Compound>();
+    std::vector<ShapeSpec> v;
     for (int i = 0; i < n; i++) {
       if (shapes[i].kind == GH_SHAPE_MESH) throw Error(Error::Other, "gp_compound_from_shapes takes primitives only");
       ShapeSpec s;
       s.kind = shapes[i].kind;
       for (int k = 0; k < 3; k++) { s.params[k] = shapes[i].params[k]; s.t[k] = shapes[i].t[k]; }
       for (int k = 0; k < 4; k++) s.q[k] = shapes[i].q[k];
-      c->shapes.push_back(s);
+      v.push_back(s);
     }
+    auto c = std::make_unique<Compound>(std::move(v));
     *out = reinterpret_cast<gp_compound*>(c.release());
     return GP_OK;
   });
 }
 
 void gp_compound_destroy(gp_compound* c) { delete reinterpret_cast<Compound*>(c); }
-int gp_compound_size(const gp_compound* c) { return (int)reinterpret_cast<const Compound*>(c)->shapes.size(); }
+int gp_compound_size(const gp_compound* c) { return (int)reinterpret_cast<const Compound*>(c)->shapes().size(); }
 
 int gp_using_joints(gp_planner* p, const char* end_joint, int32_t* out, int cap) {
   GP_BOX(p);

@@ -66,7 +66,7 @@ class JointPathPlanner:
         for i in using:
             driven.update(k for k, n in enumerate(self.collision_check_robot.nodes) if n.mimic_parent == i)
         frozen = tuple((k, p) for k, p in enumerate(self.positions) if k not in driven)
-        key = (using, id(objects), frozen, self.collision_checker.prediction, tuple(self.self_collision_pairs))
+        key = (using, objects.uid if objects is not None else 0, frozen, self.collision_checker.prediction, tuple(self.self_collision_pairs))
         sc = self._scenes.get(key)
         if sc is None:
             for k, p in enumerate(self.positions):
@@ -114,12 +114,14 @@ class JointPathPlanner:
         return not self.has_any_colliding(objects)
 
     def has_any_colliding(self, objects: D.Compound) -> bool:
-        f = self._scene(self._all(), objects).check_batch(self._current(self._all()), D.GH_CHECK_ENV)
+        # no limit gate: the reference evaluates distances on whatever state the chain holds (:86-98)
+        f = self._scene(self._all(), objects).check_batch(self._current(self._all()),
+                                                          D.GH_CHECK_ENV | D.GH_CHECK_NO_LIMITS)
         return bool(f[0] & D.GH_FLAG_ENV)
 
     def colliding_link_names(self, objects: D.Compound) -> List[str]:
         sc = self._scene(self._all(), objects)
-        m = sc.link_hits(self._current(self._all()))[0]
+        m = sc.link_hits(self._current(self._all()), D.GH_CHECK_NO_LIMITS)[0]
         names = []
         for o in range(m.shape[0]):                       # obstacle-major, duplicates kept
             for k, n in enumerate(self.collision_check_robot.nodes):
@@ -133,12 +135,13 @@ class JointPathPlanner:
         return not self.has_any_colliding_with_self()
 
     def has_any_colliding_with_self(self) -> bool:
-        f = self._scene(self._all(), None).check_batch(self._current(self._all()), D.GH_CHECK_SELF)
+        f = self._scene(self._all(), None).check_batch(self._current(self._all()),
+                                                       D.GH_CHECK_SELF | D.GH_CHECK_NO_LIMITS)
         return bool(f[0] & D.GH_FLAG_SELF)
 
     def colliding_link_names_with_self(self) -> List[Tuple[str, str]]:
         sc = self._scene(self._all(), None)
-        m = sc.self_hits(self._current(self._all()))[0]
+        m = sc.self_hits(self._current(self._all()), D.GH_CHECK_NO_LIMITS)[0]
         return [pn for p, pn in enumerate(sc.pair_names) if (int(m[p >> 6]) >> (p & 63)) & 1]
 
     # -- batched forms: what the GPU is for -------------------------------------------------------

@@ -67,8 +67,13 @@ enum {
   GH_FLAG_LIMIT = 4 /* set_joint_positions Err(_)   joint_path_planner.rs:77-82   */
 };
 
-/* `what` argument: which predicates to evaluate */
-enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2 };
+/* `what` argument: which predicates to evaluate.
+ * GH_CHECK_NO_LIMITS: skip the joint-limit gate (GH_FLAG_LIMIT is never set and collisions are evaluated
+ * for every configuration): has_any_colliding, has_any_colliding_with_self and colliding_link_names*
+ * (joint_path_planner.rs:86-110,123-134) never look at the limits, they read whatever state the chain
+ * holds; only is_feasible* goes through set_joint_positions (:77,:114).
+ * Every entry point ignores bits of `what` that are not declared in this header. */
+enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2, GH_CHECK_NO_LIMITS = 0x10 };
 /* optional `what` bits that only choose HOW the batch is evaluated; the result
  * bytes are identical either way (tests/test_gpu_pipeline.py).  Without them
  * a scene with a broadphase grid (>= 32 obstacles) takes the multi-kernel
@@ -202,13 +207,15 @@ int gh_fk_batch_dev(gh_scene* scene, const void* q_dev, size_t n, void* poses_de
  * 64-bit words; bit k of the mask for (config i, obstacle o) is set when node k
  * would be yielded by check_env for obstacle o.  Decoding obstacle-major, then
  * ascending node index, reproduces the reference's Vec<String> with its
- * duplicates.  Limit violations yield all-zero masks. */
-int gh_link_hits(gh_scene* scene, const void* q, size_t n, uint64_t* link_mask);
+ * duplicates.  what: 0, or GH_CHECK_NO_LIMITS for the reference's own behaviour
+ * (no limit check at all); without it a limit violation yields all-zero masks,
+ * the batched counterpart of is_feasible's early `false`. */
+int gh_link_hits(gh_scene* scene, const void* q, size_t n, uint32_t what, uint64_t* link_mask);
 int gh_link_mask_words(const gh_scene* scene);
 
 /* Replaces colliding_link_names_with_self (joint_path_planner.rs:130-134).
  * pair_mask: [n][ceil(P/64)] words; bit p set when self pair p is yielded. */
-int gh_self_hits(gh_scene* scene, const void* q, size_t n, uint64_t* pair_mask);
+int gh_self_hits(gh_scene* scene, const void* q, size_t n, uint32_t what, uint64_t* pair_mask);
 
 /* Instrumented run (pairs culled / SAT'd / exact-tested; SURVEY.md 8d's s,g). */
 int gh_check_batch_counted(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,

@@ -43,8 +43,8 @@ def lib():
         L.orc_check_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8,
                                       C.c_void_p, C.c_void_p]
         L.orc_fk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.orc_link_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.orc_self_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_link_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.orc_self_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         L.orc_distance.restype = C.c_double
         L.orc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_distance_bounds.restype = C.c_double
@@ -119,18 +119,18 @@ class OracleScene:
         lib().orc_fk(self.h, _ptr(q), q.shape[0], _ptr(poses))
         return poses
 
-    def link_hits(self, q):
+    def link_hits(self, q, what=0):
         q = self._q(q)
         W = (self.n_nodes + 63) // 64
         m = np.zeros((q.shape[0], self.n_obstacles, W), np.uint64)
-        lib().orc_link_hits(self.h, _ptr(q), q.shape[0], _ptr(m))
+        lib().orc_link_hits(self.h, _ptr(q), q.shape[0], what, _ptr(m))
         return m
 
-    def self_hits(self, q):
+    def self_hits(self, q, what=0):
         q = self._q(q)
         W = max((self.n_pairs + 63) // 64, 1)
         m = np.zeros((q.shape[0], W), np.uint64)
-        lib().orc_self_hits(self.h, _ptr(q), q.shape[0], _ptr(m))
+        lib().orc_self_hits(self.h, _ptr(q), q.shape[0], what, _ptr(m))
         return m
 
 

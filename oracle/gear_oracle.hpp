@@ -977,7 +977,10 @@ struct Scene {
     initial_positions(pos);
     std::vector<Iso<T>> world;
     if (band) band[0] = band[1] = std::numeric_limits<T>::max();
-    if (!set_joint_positions(q, pos)) return GH_FLAG_LIMIT;
+    // GH_CHECK_NO_LIMITS: has_any_colliding / has_any_colliding_with_self never look at the limits
+    // (joint_path_planner.rs:86-98,123-128); they read whatever state the chain holds
+    if (what & GH_CHECK_NO_LIMITS) set_joint_positions_unchecked(q, pos);
+    else if (!set_joint_positions(q, pos)) return GH_FLAG_LIMIT;
     uint8_t f = 0;
     if (faithful) {
       if (what & GH_CHECK_ENV)

@@ -75,7 +75,7 @@ static void do_fk(const Scene<T>& s, const T* q, size_t n, T* poses) {
 // colliding_link_names (joint_path_planner.rs:100-110): per obstacle, the
 // DFS-ordered nodes check_env yields, as bit masks [n][O][W].
 template <class T>
-static void do_link_hits(const Scene<T>& s, const T* q, size_t n, uint64_t* masks) {
+static void do_link_hits(const Scene<T>& s, const T* q, size_t n, uint32_t what, uint64_t* masks) {
   int D = s.dof();
   size_t O = s.obstacles.size();
   size_t W = (s.nodes.size() + 63) / 64;
@@ -84,7 +84,8 @@ static void do_link_hits(const Scene<T>& s, const T* q, size_t n, uint64_t* mask
   std::memset(masks, 0, n * O * W * sizeof(uint64_t));
   for (size_t i = 0; i < n; i++) {
     s.initial_positions(pos);
-    if (!s.set_joint_positions(q + i * D, pos)) continue;
+    if (what & GH_CHECK_NO_LIMITS) s.set_joint_positions_unchecked(q + i * D, pos);
+    else if (!s.set_joint_positions(q + i * D, pos)) continue;
     for (size_t o = 0; o < O; o++) {
       s.update_transforms(pos, world);
       uint64_t* m = masks + (i * O + o) * W;
@@ -96,7 +97,7 @@ static void do_link_hits(const Scene<T>& s, const T* q, size_t n, uint64_t* mask
 
 // colliding_link_names_with_self (joint_path_planner.rs:130-134)
 template <class T>
-static void do_self_hits(const Scene<T>& s, const T* q, size_t n, uint64_t* masks) {
+static void do_self_hits(const Scene<T>& s, const T* q, size_t n, uint32_t what, uint64_t* masks) {
   int D = s.dof();
   size_t W = (s.pairs.size() + 63) / 64;
   std::vector<T> pos;
@@ -104,7 +105,8 @@ static void do_self_hits(const Scene<T>& s, const T* q, size_t n, uint64_t* mask
   std::memset(masks, 0, n * W * sizeof(uint64_t));
   for (size_t i = 0; i < n; i++) {
     s.initial_positions(pos);
-    if (!s.set_joint_positions(q + i * D, pos)) continue;
+    if (what & GH_CHECK_NO_LIMITS) s.set_joint_positions_unchecked(q + i * D, pos);
+    else if (!s.set_joint_positions(q + i * D, pos)) continue;
     s.update_transforms(pos, world);
     uint64_t* m = masks + i * W;
     s.check_self(world, [&](int p) { m[p >> 6] |= 1ull << (p & 63); return true; }, nullptr, nullptr);
@@ -174,19 +176,19 @@ int orc_fk(void* h, const void* q, size_t n, void* poses) {
   return 0;
 }
 
-int orc_link_hits(void* h, const void* q, size_t n, uint64_t* masks) {
+int orc_link_hits(void* h, const void* q, size_t n, uint32_t what, uint64_t* masks) {
   OrcScene* s = (OrcScene*)h;
   if (!s) return -1;
-  if (s->precision == 32) do_link_hits(*s->s32, (const float*)q, n, masks);
-  else do_link_hits(*s->s64, (const double*)q, n, masks);
+  if (s->precision == 32) do_link_hits(*s->s32, (const float*)q, n, what, masks);
+  else do_link_hits(*s->s64, (const double*)q, n, what, masks);
   return 0;
 }
 
-int orc_self_hits(void* h, const void* q, size_t n, uint64_t* masks) {
+int orc_self_hits(void* h, const void* q, size_t n, uint32_t what, uint64_t* masks) {
   OrcScene* s = (OrcScene*)h;
   if (!s) return -1;
-  if (s->precision == 32) do_self_hits(*s->s32, (const float*)q, n, masks);
-  else do_self_hits(*s->s64, (const double*)q, n, masks);
+  if (s->precision == 32) do_self_hits(*s->s32, (const float*)q, n, what, masks);
+  else do_self_hits(*s->s64, (const double*)q, n, what, masks);
   return 0;
 }
 

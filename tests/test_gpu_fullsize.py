@@ -12,7 +12,7 @@ from gear_amd import descriptors as D
 from gear_amd import engine
 from gear_amd import workloads as W
 from oracle import binding as orc
-from tests.parity import compare_flags
+from tests.parity import adjudicate, compare_flags, record
 
 pytestmark = pytest.mark.gpu
 
@@ -40,9 +40,13 @@ def test_metric_scene_multi_chunk_batch(prec):
     assert rates[0] > 0.3 and rates[1] > 0.1 and rates[2] > 0.001, rates
     # the oracle on a bounded sample spread over all chunks
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
-    idx = np.linspace(0, n - 1, 192).astype(np.int64)
-    want, band = ora.check(np.ascontiguousarray(q[idx]), BOTH, threads=16)
+    idx = np.linspace(0, n - 1, 1024).astype(np.int64)
+    qs = np.ascontiguousarray(q[idx])
+    want, band = ora.check(qs, BOTH, threads=16)
     rep = compare_flags(got[idx], want, band, prec)
+    if prec == 32:
+        adjudicate(rep, got[idx], want, qs, BOTH, orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64))
+    record(f"metric_scene_multi_chunk_batch[f{prec}]", rep)
     assert rep["outside"] == 0, rep
 
 
@@ -59,8 +63,10 @@ def test_config1_sample_urdf_1m(sample_robot, obstacles_robot):
     lim = (got & 4) != 0
     assert lim.any() and (got[lim] == 4).all()             # a limit violation reports nothing else
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 32)
-    want, band = ora.check(q[:2000], BOTH, threads=16)
-    rep = compare_flags(got[:2000], want, band, 32)
+    want, band = ora.check(q[:20000], BOTH, threads=16)
+    rep = compare_flags(got[:20000], want, band, 32)
+    adjudicate(rep, got[:20000], want, q[:20000], BOTH, orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64))
+    record("config1_sample_urdf_1m[f32]", rep)
     assert rep["outside"] == 0, rep
 
 

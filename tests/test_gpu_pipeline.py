@@ -8,7 +8,7 @@ from gear_amd import descriptors as D
 from gear_amd import engine
 from gear_amd import workloads as W
 from oracle import binding as orc
-from tests.parity import compare_flags
+from tests.parity import check_flags
 
 pytestmark = pytest.mark.gpu
 
@@ -47,11 +47,8 @@ def test_pipeline_matches_oracle(prec):
     hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
     q = w.configs(3000, seed=22, dtype=hip.dtype, overshoot=0.01)
-    got = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE)
-    want, band = ora.check(q, BOTH, threads=16)
-    rep = compare_flags(got, want, band, prec)
-    print(prec, rep)
-    assert rep["outside"] == 0, rep
+    ora64 = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64) if prec == 32 else None
+    check_flags(f"pipeline_matches_oracle[f{prec}]", hip, ora, q, BOTH | D.GH_PATH_PIPELINE, prec, ora64)
 
 
 def test_pipeline_queue_overflow_is_rechecked():
@@ -79,9 +76,8 @@ def test_small_batches_default_path_equals_fused(prec):
                 got = hip.check_batch(q[:n], what)
                 assert (got == hip.check_batch(q[:n], what | D.GH_PATH_FUSED)).all(), (w.name, n, what)
         ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
-        want, band = ora.check(q[:300], BOTH, threads=16)
-        rep = compare_flags(hip.check_batch(q[:300], BOTH), want, band, prec)
-        assert rep["outside"] == 0, rep
+        ora64 = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64) if prec == 32 else None
+        check_flags(f"small_batches_default_path[{w.name},f{prec}]", hip, ora, q[:300], BOTH, prec, ora64)
 
 
 @pytest.mark.parametrize("prec", [32, 64])

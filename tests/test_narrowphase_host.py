@@ -122,3 +122,37 @@ def test_nonconvex_mesh_rejected():
     v = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
     open_tris = [(0, 1, 2), (0, 1, 3), (0, 2, 3)]
     assert harness.pair_within(ShapeSpec.mesh(v, open_tris), ShapeSpec.ball(0.1, (5, 5, 5)), MARGIN, 64) == -5
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_gjk_iteration_cap_is_conservative(prec):
+    """The reference turns GJK non-convergence into distance 0, i.e. colliding (ncollide3d
+    distance_support_map_support_map; restated in oracle/gear_oracle.hpp distance_support_maps).  The
+    product's margin query must leave through its iteration cap on the same side.  A build of the
+    narrow phase whose cap is ONE iteration (tests/harness.py lib_capped) forces that exit: a pair the
+    full query proves free after several iterations must come back "within" from the capped build, and
+    no pair may ever go from "within" to "free"."""
+    rng = np.random.default_rng(77)
+    flipped = same = 0
+    for k in range(400):
+        a = rand_shape(rng, "cyl" if k % 2 else "mesh", 0.2)
+        b = rand_shape(rng, ("box", "ball", "cyl")[k % 3], 0.2)
+        full = harness.pair_within(a, b, MARGIN, prec)
+        capped = harness.pair_within(a, b, MARGIN, prec, capped=True)
+        assert full in (0, 1) and capped in (0, 1)
+        assert capped >= full, (k, full, capped)       # the cap never frees a colliding pair
+        if capped != full:
+            flipped += 1
+            # such a pair is genuinely free by the oracle, clear of the band: the flip is the cap, not the geometry
+            assert orc.distance(a, b, prec) > MARGIN + BAND[prec]
+        else:
+            same += 1
+    print(f"f{prec}: {flipped} free pairs reported within by the one-iteration build, {same} unchanged")
+    assert flipped > 10 and same > 10
+    # a crafted one: a ball off the side face of the prism, 5.5 mm beyond the margin, reachable only
+    # through the exact stage (its bounding cube overlaps the prism's bounding box near the box corner)
+    cyl = ShapeSpec.cylinder(0.1, 0.4)
+    ball = ShapeSpec.ball(0.01, (0.125 * math.cos(math.radians(42)), 0.125 * math.sin(math.radians(42)), 0.0))
+    assert orc.distance(cyl, ball, prec) > MARGIN + 1e-3
+    assert harness.pair_within(cyl, ball, MARGIN, prec) == 0
+    assert harness.pair_within(cyl, ball, MARGIN, prec, capped=True) == 1
