@@ -26,6 +26,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_ablate(defines=("GEAR_HIP_ABLATE",), name="libgear_hip_ablate.so", verbose: bool = False) -> str:
+    """The profiling build tools/ablate_*.py and tools/attrib_sweep.sh load through GEAR_HIP_LIB: the same
+    library with the ablation bits of `what` compiled in (they return WRONG flags on purpose; the product
+    build masks `what` to the declared bits and contains none of that code)."""
+    out = os.path.join(_HERE, "..", "build", name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize",
+           "-Wno-unused-function"] + ["-D" + d for d in defines] + ["-o", out, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 HOST_LIB_PATH = os.path.join(_HERE, "libgear_host.so")
 HOST_SOURCES = [os.path.join(_HERE, "host", f) for f in ("gear_host_capi.cpp", "gear_host.hpp")]
 HOST_HEADER = os.path.join(_HERE, "..", "include", "gear_host.h")

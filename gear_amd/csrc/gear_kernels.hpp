@@ -135,7 +135,13 @@ __device__ void node_world(const Views<T>& V, int k, const T* qrow, const PoseSt
     if (nd->joint_type == JT_ROT) { s = sc[(2 * k) * kWave]; c = sc[(2 * k + 1) * kWave]; }
     cur = fk_step_sc(parent, ot, oq, axis, nd->joint_type, pos, s, c);
   } else {
+#ifdef GEAR_HIP_ABLATE_SINCOS  // attribution build (tools/attrib_sweep.sh): library sincosf instead of the f64-rounded one
+    T s = T(0), c = T(1);
+    if (nd->joint_type == JT_ROT) { s = sin(pos / T(2)); c = cos(pos / T(2)); }
+    cur = fk_step_sc(parent, ot, oq, axis, nd->joint_type, pos, s, c);
+#else
     cur = fk_step(parent, ot, oq, axis, nd->joint_type, pos);
+#endif
   }
   int ss = nd->save_slot;
   if (ss >= 0) st.put(ss, cur);

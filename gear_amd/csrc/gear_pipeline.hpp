@@ -449,7 +449,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
         if (other != s) po = first.get(sp_first_slot[other]);
         const V3<T> d = ws.t - po.t;  // (c1 - c2) or (c2 - c1): the squares are the same
         const T rr = V.spair_r[p];
-        const bool hit = push_ok && dot(d, d) < rr * rr;
+        const bool hit = push_ok && dot(d, d) < rr * rr && !GEAR_DBG(what, 0x400u);
         const unsigned long long hb = __ballot(hit);
         if (hb == 0) continue;
         const unsigned tot = 2u * (unsigned)__popcll(hb);
@@ -512,6 +512,7 @@ k_sweep_grid(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pi
           if (ex * ex + ey * ey + ez * ez >= oc[j].r * oc[j].r) h &= ~(1u << j);
         }
       }
+      if (GEAR_DBG(what, 0x400u)) h = 0;  // profiling ablation: no compaction, no stores
       const unsigned nl = (unsigned)__popc(h);
       if (__ballot(nl != 0) != 0) {
         unsigned off, tot;
