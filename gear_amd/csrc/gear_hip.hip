@@ -85,12 +85,38 @@ struct PinBuf {
   }
 };
 constexpr size_t kZeroCopyMax = 4096;  // configurations (and edges) up to which a host-buffer call runs in place
-bool zero_copy_ok() {  // GEAR_HIP_ZERO_COPY=0: always copy (measuring aid)
-  static const bool v = [] { const char* e = getenv("GEAR_HIP_ZERO_COPY"); return !(e && atoi(e) == 0); }();
-  return v;
-}
 
 constexpr int kMaxSets = 4;
+
+// Tuning and test hooks.  Read from the environment ONCE, when a scene is created; no entry point looks
+// at the environment afterwards.
+struct Knobs {
+  size_t pipe_chunk = size_t(1) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass
+  int pipe_streams = kMaxSets;          // GEAR_HIP_PIPE_STREAMS: 1 keeps every chunk on the caller's stream
+  size_t exact_cap = 0;                 // GEAR_HIP_EXACT_CAP: exact entries per sweep wavefront (tests force re-checks with it)
+  bool zero_copy = true;                // GEAR_HIP_ZERO_COPY=0: host-buffer calls always copy (measuring aid)
+  bool sweep_clds = true;               // GEAR_HIP_SWEEP_CLDS=0: cull table never in LDS
+  int sweep_waves = 0;                  // GEAR_HIP_SWEEP_WAVES: wavefronts per sweep workgroup (0: chosen by LDS use)
+  bool n2_mlds = true;                  // GEAR_HIP_N2_MLDS=0: mesh table never in LDS
+  bool n2_hist = false;                 // GEAR_HIP_N2_HIST: histogram of GJK iterations (profiling)
+  bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
+  static Knobs from_env() {
+    Knobs k;
+    auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 0) : dflt; };
+    long long x = num("GEAR_HIP_PIPE_CHUNK", 0);
+    if (x >= 4096 && x <= (1ll << 24)) k.pipe_chunk = ((size_t)x + kWave - 1) / kWave * kWave;
+    x = num("GEAR_HIP_PIPE_STREAMS", kMaxSets);
+    k.pipe_streams = (int)(x < 1 ? 1 : x > kMaxSets ? kMaxSets : x);
+    k.exact_cap = (size_t)std::max<long long>(0, num("GEAR_HIP_EXACT_CAP", 0));
+    k.zero_copy = num("GEAR_HIP_ZERO_COPY", 1) != 0;
+    k.sweep_clds = num("GEAR_HIP_SWEEP_CLDS", 1) != 0;
+    k.sweep_waves = (int)num("GEAR_HIP_SWEEP_WAVES", 0);
+    k.n2_mlds = num("GEAR_HIP_N2_MLDS", 1) != 0;
+    k.n2_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;
+    k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
+    return k;
+  }
+};
 
 struct gh_scene {
   int precision = 32, device = 0;
@@ -106,12 +132,13 @@ struct gh_scene {
   PinBuf hq, hflags, hedges, hfirst;  // small host-buffer calls run on these in place
   // pipeline workspace (gear_pipeline.hpp): several sets, so that consecutive chunks of one call can be
   // in flight together (set 0 on the caller's stream, set k on aux[k])
-  struct PipeBufs { DevBuf hdr, items, hit, exact, pc, pstore, stamps; } pw[kMaxSets];
+  struct PipeBufs { DevBuf hit, xcnt, xkey, xpose_a, xpose_b, fq, pc; } pw[kMaxSets];
   hipStream_t aux[kMaxSets] = {};  // aux[0] unused: set 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSets] = {};
   int last_sets = 0;  // workspace sets the last pipeline call used
-  unsigned last_cap2 = 0;
-  unsigned item_cap = 1024;  // survivor items per sweep wave before the fused path takes the wave over
+  unsigned exact_cap = 128;  // exact entries per sweep wavefront before the fused path takes the wavefront over
+  bool has_mesh = false;
+  Knobs knobs;
   CountersDev* counters = nullptr;
   size_t elem() const { return precision == 32 ? 4 : 8; }
 };
@@ -177,13 +204,16 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   sc->D = S.n_cols; sc->N = S.n_nodes; sc->L = S.n_shapes; sc->O = S.n_obs; sc->P = S.n_pairs;
   sc->n_slots = S.n_slots;
   sc->max_shape_node = H.rshapes.empty() ? -1 : H.rshapes.back().node;
-  // survivors per configuration grow with the number of obstacles in reach: 16 per configuration for up
-  // to 256 obstacles, proportionally more for denser scenes (GEAR_HIP_ITEM_CAP overrides; a region that
-  // still overflows is re-checked by the fused kernel)
+  S.all_blk = H.all_blk;
+  // Exact entries per sweep wavefront (64 configurations).  Box / ball scenes hand the exact stage the rare
+  // box pairs whose best axis shows a gap inside the margin; with meshes (URDF cylinders included) every
+  // candidate whose bounding boxes are closer than the margin goes there.  A wavefront that needs more is
+  // re-checked by the fused kernel (GEAR_HIP_EXACT_CAP overrides: tests force that).
+  sc->has_mesh = !H.verts.empty();
   {
-    size_t cap = 1024 * std::max<size_t>(1, (H.oshapes.size() + 255) / 256);
-    if (const char* e = getenv("GEAR_HIP_ITEM_CAP")) cap = (size_t)strtoull(e, nullptr, 0);
-    sc->item_cap = (unsigned)std::min<size_t>(std::max<size_t>(cap, 64), kMaxItemCap);
+    size_t cap = sc->has_mesh ? 512 : 128;
+    if (sc->knobs.exact_cap) cap = sc->knobs.exact_cap;
+    sc->exact_cap = (unsigned)std::min<size_t>(std::max<size_t>(cap, 1), 4096);
   }
   return GH_OK;
 }
@@ -264,99 +294,105 @@ void launch_check(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, ui
 }
 
 // ---- the pipeline (gear_pipeline.hpp) ------------------------------------------------------------
-constexpr size_t kPipeChunkDefault = size_t(1) << 20;  // configurations per pipeline pass
-size_t pipe_chunk() {  // GEAR_HIP_PIPE_CHUNK overrides (tuning aid)
-  static const size_t v = [] {
-    const char* e = getenv("GEAR_HIP_PIPE_CHUNK");
-    size_t x = e ? (size_t)strtoull(e, nullptr, 0) : 0;
-    if (x < 4096 || x > (size_t(1) << 24)) x = kPipeChunkDefault;
-    return (x + kWave - 1) / kWave * kWave;
-  }();
-  return v;
-}
-// Scenes with a broadphase grid take the pipeline at every batch size: an RRT line of a few hundred
-// samples is 55-70 us through its four small launches against ~100 us for the fused kernel, whose one
-// wavefront sweeps all L x O pairs and runs an exact stage of mixed pair classes.  Scenes without a grid
-// (fewer than 32 obstacles) keep the fused kernel below kPipeMin configurations.
-constexpr size_t kPipeMin = size_t(1) << 14;
+// Every scene whose sweep fits the LDS takes the pipeline at every batch size: an RRT line of a few hundred
+// samples costs three small launches against ~100 us for the fused kernel, whose one wavefront sweeps all
+// L x O pairs and runs an exact stage of mixed pair classes.
 constexpr size_t kMultiStreamMin = size_t(3) << 20;  // batches from here on rotate their chunks over several streams
 constexpr uint32_t kForceFused = 0x1000u, kForcePipe = 0x2000u;  // `what` bits for tests and profiling
 constexpr uint32_t kNoGrid = 0x4000u;                             // pipeline without the broadphase grid
+constexpr size_t kLdsCu = 160 * 1024;
 
-template <class T, int K>
-void launch_sweep_k(const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, const PipeWs<T>& W, int lds_centres,
-                    int max_node, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((k_sweep<T, K>), dim3(grid_for(cnt)), dim3(kWave), lds, st, S, q, cnt, what, W, lds_centres,
-                     max_node);
-}
+// LDS layout of one k_sweep_n1 launch (see the kernel): cull table + robot hot table per workgroup, then
+// per wavefront the FK branch slots, the poses of the "earlier" self-pair shapes, the ring and the hit words
+struct SweepPlan {
+  bool ok = false, clds = false;
+  unsigned table = 0, per_wave = 0, first = 0;
+  int waves = 4;
+  size_t lds() const { return table + rhot + (size_t)per_wave * waves; }
+  unsigned rhot = 0;
+};
 
-// GEAR_HIP_PIPE_STREAMS=1 keeps every chunk on the caller's stream (tuning aid; 1..kMaxSets)
-int pipe_streams() {
-  static const int v = [] {
-    const char* e = getenv("GEAR_HIP_PIPE_STREAMS");
-    const int x = e ? atoi(e) : kMaxSets;
-    return x < 1 ? 1 : x > kMaxSets ? kMaxSets : x;
-  }();
-  return v;
+template <class T>
+SweepPlan plan_sweep(const gh_scene* sc, const SceneDev<T>& S, bool do_env, bool do_self) {
+  SweepPlan best;
+  const size_t slot_bytes = (size_t)S.n_slots * 7 * kWave * sizeof(T);
+  const size_t first_bytes = do_self ? (size_t)S.n_first * 3 * kWave * sizeof(T) : 0;  // centres; the rotations wait in memory
+  const size_t per_wave = (slot_bytes + first_bytes + (size_t)kRing * 8 * sizeof(T) + 32 + 15) / 16 * 16;
+  const size_t rhot = ((size_t)S.n_shapes * 4 * sizeof(T) + 15) / 16 * 16;
+  const size_t table = ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16;
+  const size_t reg_waves = sizeof(T) == 4 ? 16 : 8;  // wavefronts per CU the registers allow (128 / 215 VGPRs)
+  // The cull table in LDS takes the cell blocks' record fetches (and the re-reads of the per-hit passes) off
+  // the texture-address path, which is what this kernel otherwise queues on: it wins even where it costs a
+  // resident wavefront or two, so it is taken whenever the table is at most 16 KB and the workgroup still
+  // fits; the workgroup size is then the one that keeps most wavefronts resident.
+  const bool want_clds = do_env && sc->knobs.sweep_clds && table <= 16 * 1024;
+  size_t best_occ = 0;
+  for (int clds = want_clds ? 1 : 0; clds >= 0 && !best.ok; clds--) {
+    for (int wv : {4, 2, 1}) {
+      if (sc->knobs.sweep_waves && wv != sc->knobs.sweep_waves) continue;
+      const size_t wg = (clds ? table : 0) + rhot + per_wave * wv;
+      if (wg > kLdsCu) continue;
+      const size_t occ = std::min(reg_waves, kLdsCu / wg * wv);
+      if (occ > best_occ) {  // ties: the larger workgroup (one table copy serves more wavefronts)
+        best_occ = occ;
+        best.ok = true;
+        best.clds = clds != 0;
+        best.table = clds ? (unsigned)table : 0u;
+        best.rhot = (unsigned)rhot;
+        best.per_wave = (unsigned)per_wave;
+        best.first = (unsigned)first_bytes;
+        best.waves = wv;
+      }
+    }
+  }
+  return best;
 }
 
 template <class T>
 int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags,
                  hipStream_t st) {
-  // a wave's queue region holds item_cap survivors; keep the whole queue near 1 GiB and the wave index
-  // inside the bits an exact entry leaves for it
-  const size_t max_waves = std::min<size_t>((size_t(1) << 30) / ((size_t)sc->item_cap * 8 * sizeof(T)), (size_t)kMaxPipeWaves);
-  size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, pipe_chunk(), std::max<size_t>(max_waves, 64) * kWave});
+  const bool do_self = (what & 2u) && S.n_spairs > 0;
+  const bool do_env = (what & 1u) && S.n_obs > 0;
+  const SweepPlan sp = plan_sweep<T>(sc, S, do_env, do_self);
+  if (!sp.ok) return fail(GH_ERR_TOO_LARGE, "internal: pipeline chosen for a scene whose sweep does not fit the LDS");
+  const unsigned capw = sc->exact_cap;
+  // keep a chunk's exact arrays near 1 GiB at most
+  const size_t entry_bytes = 8 + 8 * sizeof(T) * (do_self ? 2 : 1);
+  const size_t max_waves = std::max<size_t>((size_t(1) << 30) / (entry_bytes * capw), 64);
+  size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, sc->knobs.pipe_chunk, max_waves * kWave, (size_t)1 << 27});
   // the fused kernel is the last stage (flag conversion + re-checks): it needs its own pose columns
   StorePlan plan = plan_store(sc, true);
   // Consecutive chunks are independent.  With several workspace sets they rotate over the caller's
-  // stream and the aux streams (fork / join through events), so that one chunk's narrow phase, which
+  // stream and the aux streams (fork / join through events), so that one chunk's exact stage, which
   // cannot fill the chip, overlaps the next chunk's sweep.
-  // Forking onto the scene's streams and joining back costs ~0.1 ms per call whatever the size (measured:
-  // 128k configurations 105 us on one stream, 200 us on four; 1M 344 vs 452 us; 4M 1358 vs 1290 us), so
-  // only batches of at least kMultiStreamMin configurations and two chunks rotate over several streams.
-  int n_sets = (!plan.global && n >= kMultiStreamMin) ? pipe_streams() : 1;
+  // Forking onto the scene's streams and joining back costs ~0.1 ms per call whatever the size, so only
+  // batches of at least kMultiStreamMin configurations and two chunks rotate over several streams.
+  int n_sets = (!plan.global && n >= kMultiStreamMin) ? sc->knobs.pipe_streams : 1;
   n_sets = (int)std::min<size_t>(n_sets, (n + chunk - 1) / chunk);
   const bool two = n_sets > 1;
   const size_t waves = chunk / kWave;
-  const bool do_self = (what & 2u) && S.n_spairs > 0;
-  // the grid sweep keeps the pose of every shape that is the earlier one of a self pair in LDS and
-  // writes self survivors with both poses inline: no pose store
-  const size_t first_bytes = do_self ? (size_t)S.n_first * 7 * kWave * sizeof(T) : 0;
-  const bool do_env = (what & 1u) && S.n_obs > 0;
-  const bool use_grid = (!do_env || S.n_grids > 0) && !(what & kNoGrid) && first_bytes <= 24 * 1024;  // self only: no lookup at all
   PipeWs<T> Ws[kMaxSets];
   int rc;
   for (int k = 0; k < n_sets; k++) {
     PipeWs<T>& W = Ws[k];
     gh_scene::PipeBufs& b = sc->pw[k];
     W = PipeWs<T>{};
-    W.cap = sc->item_cap;
-    // per segment: two entries per configuration of the chunk in every pair class (a segment that runs
-    // full sends its workgroup's configurations to the fused path; GEAR_HIP_EXACT_CAP: tests force that)
-    const char* cap2_e = getenv("GEAR_HIP_EXACT_CAP");  // read per call: a test sets it for one call
-    const size_t cap2_env = cap2_e ? (size_t)strtoull(cap2_e, nullptr, 0) : (size_t)0;
-    W.cap2 = (unsigned)(cap2_env ? cap2_env : std::min<size_t>(std::max<size_t>(chunk * 2 / kSubs, 1024), 0x7fffffffu / kSegs));
-    W.stride = chunk;
-    if ((rc = b.hdr.ensure(waves * sizeof(WaveHdr))) || (rc = b.items.ensure(waves * W.cap * 8 * sizeof(T))) ||
-        (rc = b.hit.ensure(chunk * 4)) ||
-        (rc = b.exact.ensure((size_t)W.cap2 * kSegs * 4)) || (rc = b.pc.ensure(sizeof(PipeCounters))) ||
-        (do_self && !use_grid && (rc = b.pstore.ensure((size_t)S.n_shapes * 7 * chunk * sizeof(T)))))
+    W.capw = capw;
+    if ((rc = b.hit.ensure(chunk * 4)) || (rc = b.xcnt.ensure(waves * 4)) || (rc = b.xkey.ensure(waves * capw * 8)) ||
+        (rc = b.xpose_a.ensure(waves * capw * 8 * sizeof(T))) ||
+        (do_self && (rc = b.xpose_b.ensure(waves * capw * 8 * sizeof(T)))) ||
+        (do_self && (rc = b.fq.ensure(std::max<size_t>(waves * (size_t)S.n_first * kWave * 4 * sizeof(T), 16)))) ||
+        (rc = b.pc.ensure(sizeof(PipeCounters))))
       return rc;
-    W.hdr = (WaveHdr*)b.hdr.p;
-    W.items = (T*)b.items.p;
     W.hit = (unsigned*)b.hit.p;
-    W.exact = (unsigned*)b.exact.p;
+    W.xcnt = (unsigned*)b.xcnt.p;
+    W.xkey = (uint2*)b.xkey.p;
+    W.xpose_a = (T*)b.xpose_a.p;
+    W.xpose_b = do_self ? (T*)b.xpose_b.p : nullptr;
+    W.fq = do_self ? (T*)b.fq.p : nullptr;
     W.pc = (PipeCounters*)b.pc.p;
-    W.pstore = (T*)b.pstore.p;
-    static const bool want_stamps = getenv("GEAR_HIP_STAMPS") != nullptr;  // profiling aid
-    if (want_stamps) {
-      if ((rc = b.stamps.ensure(waves * 8 * sizeof(unsigned long long)))) return rc;
-      W.stamps = (unsigned long long*)b.stamps.p;
-    }
   }
   sc->last_sets = n_sets;
-  sc->last_cap2 = Ws[0].cap2;
   void* gs = nullptr;
   size_t gstride = 0;
   if (plan.global) {
@@ -364,17 +400,11 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     gs = sc->store.p;
     gstride = chunk;
   }
-  const size_t slot_bytes = (size_t)S.n_slots * 7 * kWave * sizeof(T);
-  const size_t cen_bytes = (size_t)S.n_shapes * 3 * kWave * sizeof(T);
-  const int lds_centres = do_self && cen_bytes <= 24 * 1024;
-  const int max_node = sc->max_shape_node;  // the walk stops at the last node that carries a shape
-  const size_t sc_bytes = (size_t)(max_node + 1) * 2 * kWave * sizeof(T);
-  const size_t lds = slot_bytes + sc_bytes + (lds_centres ? cen_bytes : 0);
-  const int K = pick_chunk(sc->L);
   if (two) {
     GH_HIP(hipEventRecord(sc->ev_fork, st));
     for (int k = 1; k < n_sets; k++) GH_HIP(hipStreamWaitEvent(sc->aux[k], sc->ev_fork, 0));
   }
+  const int all_blk = (what & kNoGrid) ? S.all_blk : -1;
   size_t ci = 0;
   for (size_t off = 0; off < n; off += chunk, ci++) {
     const size_t cnt = std::min(chunk, n - off);
@@ -382,51 +412,21 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     const int set = (int)(ci % (size_t)n_sets);
     const PipeWs<T>& W = Ws[set];
     hipStream_t cs = set ? sc->aux[set] : st;
-    // the sweep clears the queue counters itself; the diagnostic counters need the whole block cleared
-    static const bool hist_env = getenv("GEAR_HIP_N2_HIST") != nullptr;
-    if ((what & 0x8000u) || hist_env) GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
-    if (use_grid) {
-      // four wavefronts per workgroup; the cull table joins them in LDS when it is at most 16 KB
-      static const size_t lds_pad = [] { const char* e = getenv("GEAR_HIP_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-      static const bool clds_ok = [] { const char* e = getenv("GEAR_HIP_SWEEP_CLDS"); return !(e && atoi(e) == 0); }();  // tuning aid
-      const unsigned per_wave = (unsigned)((slot_bytes + first_bytes + lds_pad + 15) / 16 * 16);
-      const size_t table = ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16;
-      const dim3 sg_grid((unsigned)((grid_for(cnt) + kSgWaves - 1) / kSgWaves)), sg_block(kWave * kSgWaves);
-      // ... and does not cost a resident workgroup: registers allow 4 (f32) / 3 (f64) workgroups per CU
-      const size_t lds_cu = 160 * 1024, wg_plain = (size_t)per_wave * kSgWaves, reg_wgs = sizeof(T) == 4 ? 4 : 3;
-      const size_t wgs_plain = std::min(reg_wgs, lds_cu / std::max<size_t>(wg_plain, 1)), wgs_table = lds_cu / (wg_plain + table);
-      if (clds_ok && do_env && table <= 16 * 1024 && wgs_table >= wgs_plain)
-        hipLaunchKernelGGL((k_sweep_grid<T, true>), sg_grid, sg_block, table + (size_t)per_wave * kSgWaves, cs, S, qc, cnt, what, W, per_wave);
-      else
-        hipLaunchKernelGGL((k_sweep_grid<T, false>), sg_grid, sg_block, (size_t)per_wave * kSgWaves, cs, S, qc, cnt, what, W, per_wave);
-    } else {
-      switch (K) {
-        case 5: launch_sweep_k<T, 5>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
-        case 7: launch_sweep_k<T, 7>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
-        default: launch_sweep_k<T, 9>(S, qc, cnt, what, W, lds_centres, max_node, lds, cs); break;
-      }
-    }
+    if ((what & 0x8000u) || sc->knobs.n2_hist) GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
+    const unsigned n_sw = grid_for(cnt);  // sweep wavefronts
     {
-      // stage 1's compact shape table: the robot's part goes to LDS; the obstacles' part is gathered from
-      // memory (48-byte records) — staging it in LDS too (GEAR_HIP_N1_OLDS=1, <= 32 KB) measured 1-3 % slower
-      const size_t rhot = (size_t)S.n_shapes * 4 * sizeof(T), ohot = (size_t)S.n_obs * 12 * sizeof(T);
-      static const bool olds = [] { const char* e = getenv("GEAR_HIP_N1_OLDS"); return e && atoi(e) == 1; }();
-      if (olds && rhot + ohot <= 32 * 1024)
-        hipLaunchKernelGGL((k_narrow1<T, true>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot + ohot, cs, S, cnt, what, W);
+      const dim3 grid((n_sw + sp.waves - 1) / sp.waves), block(kWave * sp.waves);
+      if (sp.clds)
+        hipLaunchKernelGGL((k_sweep_n1<T, true>), grid, block, sp.lds(), cs, S, qc, cnt, what, W, sp.table, sp.per_wave, sp.first, all_blk);
       else
-        hipLaunchKernelGGL((k_narrow1<T, false>), dim3(grid_for(cnt)), dim3(kN1Threads), rhot, cs, S, cnt, what, W);
+        hipLaunchKernelGGL((k_sweep_n1<T, false>), grid, block, sp.lds(), cs, S, qc, cnt, what, W, sp.table, sp.per_wave, sp.first, all_blk);
     }
-    // one-wave workgroups, grid row = segment: enough columns for an eighth of an entry per configuration
-    // in one class (more: grid-stride); the workgroups of empty segments leave at once
-    static const size_t g2div = [] { const char* e = getenv("GEAR_HIP_N2_GRID_DIV"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)8; }();
-    const unsigned g2 = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, cnt / (g2div * kSubs * kN2Threads)));
     {
       // the mesh pools (4-wide records) join the workgroup in LDS when they are at most 48 KB
       const size_t mesh_bytes = (size_t)(S.n_verts + S.n_planes) * 4 * sizeof(T);
-      static const bool mlds_ok = [] { const char* e = getenv("GEAR_HIP_N2_MLDS"); return !(e && atoi(e) == 0); }();  // tuning aid
-      static const bool want_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;  // profiling aid
-      if (want_hist) {
-        hipLaunchKernelGGL((k_narrow2<T, false, true>), dim3(g2, kSegs), dim3(kN2Threads), 0, cs, S, what, W);
+      const dim3 grid((n_sw + kN2Tile - 1) / kN2Tile), block(kN2Threads);
+      if (sc->knobs.n2_hist) {
+        hipLaunchKernelGGL((k_narrow2<T, false, true>), grid, block, 0, cs, S, what, W, n_sw);
         GH_HIP(hipStreamSynchronize(cs));
         PipeCounters h;
         GH_HIP(hipMemcpy(&h, W.pc, sizeof(h), hipMemcpyDeviceToHost));
@@ -435,10 +435,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
           for (int k = 0; k < 48; k++) fprintf(stderr, " %u", h.hist[r][k]);
           fprintf(stderr, "\n");
         }
-      } else if (mlds_ok && mesh_bytes > 0 && mesh_bytes <= 48 * 1024)
-        hipLaunchKernelGGL((k_narrow2<T, true>), dim3(g2, kSegs), dim3(kN2Threads), mesh_bytes, cs, S, what, W);
+      } else if (sc->knobs.n2_mlds && mesh_bytes > 0 && mesh_bytes <= 48 * 1024)
+        hipLaunchKernelGGL((k_narrow2<T, true>), grid, block, mesh_bytes, cs, S, what, W, n_sw);
       else
-        hipLaunchKernelGGL((k_narrow2<T, false>), dim3(g2, kSegs), dim3(kN2Threads), 0, cs, S, what, W);
+        hipLaunchKernelGGL((k_narrow2<T, false>), grid, block, 0, cs, S, what, W, n_sw);
     }
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());
@@ -449,25 +449,6 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
       GH_HIP(hipStreamWaitEvent(st, sc->ev_join[k], 0));
     }
   }
-  if (Ws[0].stamps) {  // profiling aid: mean cycles between k_narrow1's phase stamps, first workspace set
-    GH_HIP(hipStreamSynchronize(st));
-    const size_t nw = std::min(waves, (std::min(chunk, n) + kWave - 1) / kWave);
-    std::vector<unsigned long long> h(nw * 8);
-    GH_HIP(hipMemcpy(h.data(), Ws[0].stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    // stamps written: 0 start, 1 first trip in, 2 first round computed, 3 its barrier passed, 6 all rounds
-    // and flushes done, 7 end
-    const int at[6] = {0, 1, 2, 3, 6, 7};
-    double d[6] = {0};
-    size_t cntd = 0;
-    for (size_t w = 0; w < nw; w++) {
-      if (h[w * 8 + 7] <= h[w * 8] || h[w * 8 + 2] == 0) continue;
-      for (int k = 1; k < 6; k++) d[k] += (double)(long long)(h[w * 8 + at[k]] - h[w * 8 + at[k - 1]]);
-      cntd++;
-    }
-    fprintf(stderr, "k_narrow1 stamps (mean cycles over %zu workgroups): first trip %.0f | round 1 %.0f | barrier %.0f | later rounds + flush %.0f | tail %.0f\n",
-            cntd, d[1] / cntd, d[2] / cntd, d[3] / cntd, d[4] / cntd, d[5] / cntd);
-    GH_HIP(hipMemset(Ws[0].stamps, 0, h.size() * 8));
-  }
   return GH_OK;
 }
 
@@ -476,12 +457,13 @@ int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* fla
   what &= kWhatPublic;  // undeclared bits never reach a kernel (the ablation build of tools/ keeps them)
 #endif
   if (!(sc->margin > 0)) what &= ~3u;  // distance >= 0 is never < a non-positive margin: only limits can fail
-  const size_t slot_bytes = (size_t)sc->n_slots * 7 * kWave * sc->elem();
-  const bool pipe_ok = !counted && (what & 3u) && sc->L > 0 &&
-                       slot_bytes + (size_t)(sc->max_shape_node + 1) * 2 * kWave * sc->elem() <= 32 * 1024;
-  static const bool small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;  // measuring aid: the pre-v8 rule
-  const bool has_grid = !small_fused && (sc->precision == 32 ? sc->s32.n_grids : sc->s64.n_grids) > 0;
-  if (pipe_ok && !(what & kForceFused) && (n >= kPipeMin || has_grid || (what & kForcePipe))) {
+  bool pipe_ok = !counted && (what & 3u) && sc->L > 0 && !(what & kForceFused);
+  if (pipe_ok && sc->knobs.small_fused && n < (size_t(1) << 14) && !(what & kForcePipe)) pipe_ok = false;
+  if (pipe_ok) {
+    const bool ds = (what & 2u) && sc->P > 0, de = (what & 1u) && sc->O > 0;
+    pipe_ok = sc->precision == 32 ? plan_sweep<float>(sc, sc->s32, de, ds).ok : plan_sweep<double>(sc, sc->s64, de, ds).ok;
+  }
+  if (pipe_ok) {
     if (n == 0) return GH_OK;
     return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st)
                                : pipeline_dev<double>(sc, sc->s64, (const double*)q, n, what, flags, st);
@@ -543,6 +525,7 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
   sc->precision = precision;
   sc->device = device;
   sc->margin = margin;
+  sc->knobs = Knobs::from_env();
   int rc;
   {
     Guard g(sc);
@@ -590,8 +573,7 @@ void gh_scene_destroy(gh_scene* sc) {
     }
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
     for (auto& b : sc->pw) {
-      b.hdr.release(); b.items.release(); b.hit.release(); b.exact.release();
-      b.pc.release(); b.pstore.release(); b.stamps.release();
+      b.hit.release(); b.xcnt.release(); b.xkey.release(); b.xpose_a.release(); b.xpose_b.release(); b.fq.release(); b.pc.release();
     }
   }
   delete sc;
@@ -618,7 +600,7 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   int rc;
   size_t qb = n * sc->D * sc->elem();
-  if (n <= kZeroCopyMax && zero_copy_ok()) {
+  if (n <= kZeroCopyMax && sc->knobs.zero_copy) {
     if ((rc = sc->hq.ensure(qb)) || (rc = sc->hflags.ensure(n))) return rc;
     std::memcpy(sc->hq.p, q, qb);
     if ((rc = check_dev(sc, sc->hq.d, n, what, (uint8_t*)sc->hflags.d, sc->stream, false))) return rc;
@@ -664,12 +646,10 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
     PipeCounters h;
     GH_HIP(hipMemcpy(&h, b.pc.p, sizeof(h), hipMemcpyDeviceToHost));
     out[0] += h.candidates;
-    for (int sgm = 0; sgm < kSegs; sgm++) {
-      out[1] += h.seg[sgm][0];
-      out[2] += h.seg[sgm][0] > sc->last_cap2 ? 1 : 0;
-    }
+    out[1] += h.exact;
+    out[2] += h.redo_waves;
   }
-  out[3] = sc->item_cap;
+  out[3] = sc->exact_cap;
   return GH_OK;
 }
 
@@ -712,7 +692,7 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   const size_t qb = n * sc->D * sc->elem();
-  if (n <= kZeroCopyMax && n_edges <= kZeroCopyMax && zero_copy_ok()) {
+  if (n <= kZeroCopyMax && n_edges <= kZeroCopyMax && sc->knobs.zero_copy) {
     if ((rc = sc->hq.ensure(std::max<size_t>(qb, 1))) || (rc = sc->hflags.ensure(std::max<size_t>(n, 1))) ||
         (rc = sc->hedges.ensure((n_edges + 1) * 4)) || (rc = sc->hfirst.ensure(n_edges * 4)))
       return rc;

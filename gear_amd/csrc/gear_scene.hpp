@@ -29,7 +29,7 @@ struct HostTables {
   std::vector<ShapeDev<T>> rshapes, oshapes;
   std::vector<T> ocull, ocullq;
   std::vector<PairDev> pairs;
-  std::vector<int32_t> spairs;  // flattened self shape pairs: [n][4] = s1, s2, node-pair index, 0
+  std::vector<int32_t> spairs;  // flattened self shape pairs: [n][4] = s1, s2, node-pair index, LDS slot of the earlier shape
   std::vector<T> spair_r;       // [n] bounding radii sum + margin, inflated
   std::vector<T> verts, planes;
   std::vector<GridDev<T>> grids;
@@ -39,6 +39,7 @@ struct HostTables {
   std::vector<T> hot;                                        // see SceneDev::hot
   int n_first = 0;
   int n_slots = 0;
+  int all_blk = -1;  // head block of the chain listing every obstacle, -1: no obstacles
   T margin = 0;
 };
 
@@ -227,10 +228,26 @@ template <class T>
 inline void build_grids(HostTables<T>& H, double margin) {
   const size_t O = H.oshapes.size(), L = H.rshapes.size();
   H.shape_grid.assign(L, 0);
-  if (O < 32 || L == 0) return;  // small fields are swept directly
+  H.all_blk = -1;
+  if (O == 0 || L == 0) return;
   {
     const uint32_t sentinel = (uint32_t)O, empty = sentinel | (sentinel << 16);
     H.cell_blk.assign(4, empty);  // block 0: the empty list
+    // the chain that lists EVERY obstacle (GH_PATH_NO_GRID: the brute-force cross-check of the grids)
+    H.all_blk = 1;
+    size_t pos = 0;
+    for (;;) {
+      const size_t cur = H.cell_blk.size() / 4;
+      H.cell_blk.resize((cur + 1) * 4, empty);
+      const size_t left = O - pos, take = left <= 8 ? left : 6;
+      for (size_t j = 0; j < take; j++) {
+        uint32_t& w = H.cell_blk[cur * 4 + j / 2];
+        w = (j & 1) ? ((w & 0xffffu) | ((uint32_t)(pos + j) << 16)) : ((w & 0xffff0000u) | (uint32_t)(pos + j));
+      }
+      pos += take;
+      if (pos == O) break;
+      H.cell_blk[cur * 4 + 3] = 0x80000000u | (uint32_t)(cur + 1);
+    }
   }
   std::vector<double> radii;
   for (auto& s : H.rshapes) radii.push_back((double)s.br);
@@ -480,6 +497,11 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
     H.n_first = 0;
     for (size_t s = 0; s < L; s++)
       if (H.sp_first_slot[s] == 0) H.sp_first_slot[s] = H.n_first++;
+    // a self shape pair's fourth word: LDS slot of its earlier shape (-1: both are the same shape)
+    for (size_t p = 0; p < NP; p++) {
+      const int s1 = H.spairs[4 * p], s2 = H.spairs[4 * p + 1];
+      H.spairs[4 * p + 3] = s1 == s2 ? -1 : H.sp_first_slot[(size_t)std::min(s1, s2)];
+    }
     H.sp_late_off.assign(1, 0);
     for (size_t s = 0; s < L; s++) {
       H.sp_late.insert(H.sp_late.end(), by_late[s].begin(), by_late[s].end());

@@ -97,7 +97,7 @@ struct SceneDev {
   const T* ocullq;
   int32_t n_obs_pad, pad2;
   const PairDev* pairs;
-  const int32_t* spairs;  // [n_spairs][4]: s1, s2, node-pair index, 0
+  const int32_t* spairs;  // [n_spairs][4]: s1, s2, node-pair index, LDS pose slot of the earlier shape (-1: s1 == s2)
   const T* spair_r;       // [n_spairs]: inflated bounding-radius sum + margin
   int32_t n_spairs, n_first;
   // self shape pairs grouped by the shape the FK walk reaches LATER (the sweep tests a pair when that
@@ -118,7 +118,8 @@ struct SceneDev {
   // holds six indices and the low 31 bits are the index of the next block.  Block 0 is empty (lanes
   // outside a grid read it); a grid's head blocks are contiguous from off_base, one per cell.
   const uint32_t* cell_blk;     // [n_blocks][4]
-  int32_t n_grids, pad4;
+  int32_t n_grids;
+  int32_t all_blk;  // head block of the chain that lists every obstacle (GH_PATH_NO_GRID), -1: none
   // the mesh pools once more as 4-wide records, vertices {x,y,z,0} then face planes {nx,ny,nz,offset}:
   // the exact stage (k_narrow2) copies this table to LDS when it fits, and reads a vertex or a plane
   // with one 16-byte access

@@ -159,7 +159,7 @@ class Scene:
     def pipeline_last_stats(self) -> dict:
         out = (C.c_uint64 * 4)()
         _check(lib().gh_pipeline_last_stats(self.h, out))
-        return {"candidates": int(out[0]), "exact_items": int(out[1]), "exact_overflow": int(out[2]), "item_cap": int(out[3])}
+        return {"candidates": int(out[0]), "exact_items": int(out[1]), "redo_waves": int(out[2]), "exact_cap": int(out[3])}
 
     def check_batch_counted(self, q_t, flags_t, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF) -> dict:
         c = D.gh_counters()

@@ -221,10 +221,11 @@ int gh_self_hits(gh_scene* scene, const void* q, size_t n, uint32_t what, uint64
 int gh_check_batch_counted(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
                            uint8_t* flags_dev, gh_counters* out);
 
-/* Diagnostic, no counterpart in the reference: counters of the last large-batch call on this
- * scene, summed over the last chunk of each of its (one or two) workspace sets (synchronises the device).  out[0] broadphase candidates tested (only when `what`
- * carried GH_COUNT_CANDIDATES), out[1] items that needed the exact stage, out[2] != 0 when the exact
- * queue overflowed (those configurations were re-checked), out[3] survivor-queue capacity per wave. */
+/* Diagnostic, no counterpart in the reference: counters of the last call on this scene that carried
+ * GH_COUNT_CANDIDATES in `what`, summed over the last chunk of each workspace set it used (synchronises
+ * the device).  out[0] broadphase candidates tested, out[1] items handed to the exact stage, out[2]
+ * sweep wavefronts whose exact region ran full (their configurations were re-checked by the fused
+ * kernel), out[3] exact entries a sweep wavefront may write. */
 int gh_pipeline_last_stats(gh_scene* scene, uint64_t out[4]);
 
 const char* gh_last_error(void);

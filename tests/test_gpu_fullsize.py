@@ -89,38 +89,44 @@ def test_config2_64k_edges():
     assert (flags[sub] == hip.check_batch(q[sub], D.GH_CHECK_ENV | D.GH_PATH_FUSED)).all()
 
 
-def test_tiny_queue_capacity_forces_rechecks():
-    """GEAR_HIP_ITEM_CAP=64: nearly every sweep wave overflows its queue region, so nearly every
-    configuration is decided by the fused re-check inside the pipeline's last stage."""
-    w = W.metric_workload()
-    old = os.environ.get("GEAR_HIP_ITEM_CAP")
-    os.environ["GEAR_HIP_ITEM_CAP"] = "64"
+def _scene_with_env(w, prec, **env):
+    """Tuning hooks are read once, when a scene is created."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
     try:
-        hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)   # the capacity is read at scene creation
+        return engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
     finally:
-        if old is None:
-            del os.environ["GEAR_HIP_ITEM_CAP"]
-        else:
-            os.environ["GEAR_HIP_ITEM_CAP"] = old
-    q = w.configs(100000, seed=33, overshoot=0.01)
-    got = hip.check_batch(q, BOTH)
-    assert hip.pipeline_last_stats()["item_cap"] == 64
-    ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
-    assert (got == ref.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
-def test_full_exact_queue_segments_are_rechecked():
-    """GEAR_HIP_EXACT_CAP=4: the segments of the exact queue (one set per pair class) run full almost at
-    once; the workgroups that could not append mark their configurations for the fused re-check."""
-    w = W.metric_workload()
-    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
-    q = w.configs(100000, seed=35, overshoot=0.01)
-    os.environ["GEAR_HIP_EXACT_CAP"] = "4"   # read per call
-    try:
-        got = hip.check_batch(q, BOTH)
+def test_full_exact_regions_are_rechecked():
+    """GEAR_HIP_EXACT_CAP=2: a sweep wavefront may hand only two items to the exact stage, so nearly
+    every wavefront overflows and its configurations are decided by the fused re-check inside the
+    pipeline's last stage.  The flags must not depend on that capacity."""
+    for w in (W.metric_workload(), W.ur10_workload(128)):
+        hip = _scene_with_env(w, 32, GEAR_HIP_EXACT_CAP=2)
+        q = w.configs(100000, seed=35, overshoot=0.01)
+        got = hip.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
         st = hip.pipeline_last_stats()
-    finally:
-        del os.environ["GEAR_HIP_EXACT_CAP"]
-    assert st["exact_overflow"] > 0
-    assert (got == hip.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
-    assert (got == hip.check_batch(q, BOTH)).all()
+        assert st["exact_cap"] == 2 and st["redo_waves"] > 100, st
+        ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+        assert (got == ref.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
+        assert (got == ref.check_batch(q, BOTH)).all()
+        ref.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
+        assert ref.pipeline_last_stats()["redo_waves"] == 0           # the default capacity is not reached here
+
+
+def test_sweep_workgroup_shapes_agree():
+    """The sweep runs with 4, 2 or 1 wavefronts per workgroup and with the cull table in LDS or not,
+    whichever keeps most wavefronts resident; every shape must give the same flags."""
+    w = W.metric_workload()
+    q = w.configs(70000, seed=36, overshoot=0.01)
+    ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32).check_batch(q, BOTH)
+    for env in ({"GEAR_HIP_SWEEP_WAVES": 1}, {"GEAR_HIP_SWEEP_WAVES": 2}, {"GEAR_HIP_SWEEP_WAVES": 4, "GEAR_HIP_SWEEP_CLDS": 0},
+                {"GEAR_HIP_PIPE_CHUNK": 8192}):
+        hip = _scene_with_env(w, 32, **env)
+        assert (hip.check_batch(q, BOTH) == ref).all(), env

@@ -23,11 +23,11 @@ def d(a, b, c="SQ_INSTS_VALU"):
     return round(rows[a][c] - rows[b][c], 1) if a in rows and b in rows else None
 att = {
     "total VALU per wavefront": rows.get("full", {}).get("SQ_INSTS_VALU"),
-    "oriented-box second cull (no_push - no_push_obb)": d("no_push", "no_push_obb"),
-    "compaction + survivor stores (full - no_push)": d("full", "no_push"),
+    "stage 1 of the narrow phase inside the drains (full - no_stage1)": d("full", "no_stage1"),
+    "ring pushes + drain bookkeeping (no_stage1 - no_push)": d("no_stage1", "no_push"),
+    "oriented-box second cull, per-hit passes (no_push - no_push_obb)": d("no_push", "no_push_obb"),
     "cell lookup + first cull + block loop (no_push_obb - fk_self)": d("no_push_obb", "fk_self"),
-    "self pairs: cull + LDS pose columns (fk_self - fk_only)": d("fk_self", "fk_only"),
-    "limits + FK walk + shape poses, with the f64-rounded sincos (fk_only)": rows.get("fk_only", {}).get("SQ_INSTS_VALU"),
-    "of which the f64-rounded sincos over the library's sincosf (fk_only - fk_only_libm_sincos)": d("fk_only", "fk_only_libm_sincos"),
+    "self pairs: centre cull (fk_self - fk_only)": d("fk_self", "fk_only"),
+    "limits + FK walk + shape poses (fk_only)": rows.get("fk_only", {}).get("SQ_INSTS_VALU"),
 }
 print(json.dumps(att, indent=1))

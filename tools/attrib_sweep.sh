@@ -1,8 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/attrib_sweep.sh <tag>
 # Per-region instruction attribution of the sweep kernel by differences between ablated runs of the
-# -DGEAR_HIP_ABLATE build (build/libgear_hip_ablate.so; build/libgear_hip_ablate_sincos.so additionally
-# swaps the f64-rounded sincos for the library's): one rocprofv3 --pmc pass of SQ counters per variant
+# -DGEAR_HIP_ABLATE build (build/libgear_hip_ablate.so): one rocprofv3 --pmc pass of SQ counters per variant
 # over tools/run_once.py (512k configurations of the metric scene, one stream).  tools/attrib_show.py
 # turns the passes into the table committed under profiles/.
 tag=${1:-attrib}
@@ -13,11 +12,11 @@ run() {  # label what lib
   bash $GRAFT_REPO_ROOT/tools/pmc_pass.sh $2 $tag/$1 $C || exit 1
 }
 run full        0x2003   libgear_hip_ablate.so &&
+run no_stage1   0x2203   libgear_hip_ablate.so &&
 run no_obb      0x202003 libgear_hip_ablate.so &&
 run no_push     0x2403   libgear_hip_ablate.so &&
 run no_push_obb 0x202403 libgear_hip_ablate.so &&
-run fk_self     0x2803   libgear_hip_ablate.so &&
-run fk_only     0x2801   libgear_hip_ablate.so &&
-run fk_only_libm_sincos 0x2801 libgear_hip_ablate_sincos.so &&
+run fk_self     0x2c03   libgear_hip_ablate.so &&
+run fk_only     0x2c01   libgear_hip_ablate.so &&
 run env_only    0x2001   libgear_hip_ablate.so &&
 run self_only   0x2002   libgear_hip_ablate.so
