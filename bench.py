@@ -9,7 +9,8 @@ A "step" is one pass of the hot path (gh_check_batch_dev) over one batch of
 synthetic joint configurations already resident in HBM; with N > 1 every rank
 checks its own shard of the batch (scene replicated per GPU, no data-path
 collective) and the per-config flag bytes are gathered over RCCL each step.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  At N = 1 the same line also carries the f64 figure,
+a free-space-dominant variant of the scene and the CPU baseline.
 """
 import argparse
 import json
@@ -30,12 +31,12 @@ from gear_amd import workloads as W
 
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-PIPE_MIN = 1 << 14                          # gear_hip.hip kPipeMin: scenes without a grid take the fused kernel below it
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "v8_pipeline_traffic.json")   # tools/pmc_traffic.py
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "pipeline_traffic.json")   # tools/pmc_traffic.py
+WHAT = D.GH_CHECK_ENV | D.GH_CHECK_SELF
 
 
 def measured_traffic(batch):
-    """Fabric bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    """Fabric bytes per step from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, gfx950 correction applied; tools/pmc_traffic.py), scaled to this batch.  None when
     the summary is absent: bench.py itself cannot run under the profiler."""
     try:
@@ -73,40 +74,91 @@ def device_configs(w, n, seed, dtype, device):
     return ((hi_t - lo_t) * u + lo_t).to(dtype).contiguous()
 
 
-def cpu_baseline(w, precision, what, q_gpu=None, flags_gpu=None, seconds=12.0):
+def host_threads():
+    """Threads for the CPU baseline: every CPU this process may run on (sched_getaffinity), capped by the
+    cgroup's CPU quota where one is set — threads beyond the quota are time-sliced, not added."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()
+            if a != "max":
+                quota = max(1, int(float(a) / float(b) + 0.5))
+    except (OSError, ValueError):
+        pass
+    threads = min(affinity, quota) if quota else affinity
+    return max(1, min(threads, 1000)), affinity, quota
+
+
+def cpu_baseline(w, precision, q_gpu=None, flags_gpu=None, seconds=12.0):
     """The reference's CPU path as restated by oracle/ ("port"): is_feasible-style early exits and the
     per-obstacle FK the reference does, (i) single-threaded (the reference is !Send) and (ii) one
-    independent chain per thread on the host cores available to this process.  This leg is the only
+    independent chain per thread on all host cores available to this process.  This leg is the only
     place bench.py touches oracle/; while it is here it also checks the GPU's flags of the first timed
     configurations (q_gpu, flags_gpu: host copies) against it."""
     from oracle import binding as orc
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, precision)
     dtype = np.float32 if precision == 32 else np.float64
+    cores, affinity, quota = host_threads()
     parity = None
     if q_gpu is not None:
         from tests.parity import compare_flags
-        want, band = ora.check(q_gpu, what, threads=16)
+        want, band = ora.check(q_gpu, WHAT, threads=cores)
         rep = compare_flags(flags_gpu, want, band, precision)
         parity = {kk: rep[kk] for kk in ("total", "mismatched", "in_band", "oracle_uncertified", "outside")}
     probe = w.configs(32, seed=999, dtype=dtype)
     t0 = time.perf_counter()
     ora.check(probe, faithful=True, redundant_fk=True, threads=1, want_band=False)
     rate1 = len(probe) / max(time.perf_counter() - t0, 1e-9)
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
     n1 = max(32, int(rate1 * seconds * 0.4))
     q1 = w.configs(n1, seed=1000, dtype=dtype)
     t0 = time.perf_counter()
     ora.check(q1, faithful=True, redundant_fk=True, threads=1, want_band=False)
     single = n1 / (time.perf_counter() - t0)
-    nm = max(64, int(single * cores * seconds * 0.6))
+    nm = max(64 * cores, int(single * cores * seconds * 0.6))
     qm = w.configs(nm, seed=1001, dtype=dtype)
     t0 = time.perf_counter()
     ora.check(qm, faithful=True, redundant_fk=True, threads=cores, want_band=False)
     multi = nm / (time.perf_counter() - t0)
     return {"value": multi, "unit": "configs/s", "cores": cores, "kind": "port",
+            "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
             "single_thread_value": single, "gpu_parity_spot_check": parity,
-            "sample": f"{nm} configs on {cores} threads and {n1} configs on 1 thread of the same scene and "
-                      f"input distribution; C++ restatement of gear's path (oracle/), not the Rust crate"}
+            "sample": f"{nm} configs on {cores} threads (all CPUs of sched_getaffinity, capped by the cgroup CPU quota) and "
+                      f"{n1} configs on 1 thread of the same scene and input distribution; C++ restatement of "
+                      f"gear's path (oracle/), not the Rust crate"}
+
+
+def timed_steps(scene, q, flags, stream, steps, warmup):
+    """warmup + steps calls of gh_check_batch_dev on `stream`; returns (wall seconds, mean HIP-event ms per step)."""
+    for _ in range(warmup):
+        scene.check_batch_dev(q, flags, WHAT, stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        scene.check_batch_dev(q, flags, WHAT, stream)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def side_measurement(w, precision, B, device, stream, steps, warmup, seed):
+    """One extra single-GPU figure in the same run (f64, or another scene): value, ms per step, formula frac."""
+    scene = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, precision, device=device.index)
+    dtype = torch.float32 if precision == 32 else torch.float64
+    q = device_configs(w, B, seed, dtype, device)
+    flags = torch.zeros(B, dtype=torch.uint8, device=device)
+    ns = min(B, 1 << 16)
+    counters = scene.check_batch_counted(q[:ns], flags[:ns], WHAT)
+    fpc, mix = algorithmic_flops_per_config(w, counters)
+    wall, kms = timed_steps(scene, q, flags, stream, steps, warmup)
+    rates = [float((flags & b).ne(0).float().mean()) for b in (1, 2, 4)]
+    return {"workload": w.name, "dtype": "f32" if precision == 32 else "f64", "value": B * steps / wall, "unit": "configs/s",
+            "batch": B, "ms_per_step": wall / steps * 1e3, "kernel_ms": kms,
+            "roofline_frac": fpc * B / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[precision],
+            "algorithmic_flops_per_config": fpc, "sat_per_config": mix["sat_per_config"], "exact_per_config": mix["exact_per_config"],
+            "flag_rates": {"env": rates[0], "self": rates[1], "limit": rates[2]}}
 
 
 def main():
@@ -120,6 +172,7 @@ def main():
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f64 and free-space sub-records")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,19 +186,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+        # the scene rotates a call's chunks over the caller's stream and up to three of its own; the box gives
+        # a process four hardware queues, and RCCL's stream needs one of them for the flag gather
+        os.environ.setdefault("GEAR_HIP_PIPE_STREAMS", "3")
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     w = W.metric_workload(args.obstacles)
     scene = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, args.precision, device=local_rank)
     dtype = torch.float32 if args.precision == 32 else torch.float64
-    what = D.GH_CHECK_ENV | D.GH_CHECK_SELF
     B = args.batch
     q = device_configs(w, B, seed=1234 + rank, dtype=dtype, device=device)   # this rank's shard
     flags = torch.zeros(B, dtype=torch.uint8, device=device)
     gathered = torch.zeros(B * world, dtype=torch.uint8, device=device) if world > 1 else None
     # a non-default torch stream: its handle is what the C ABI launches on, so torch.cuda.Event
-    # (HIP events on that same stream) brackets the kernel itself
+    # (HIP events on that same stream) brackets the kernels themselves
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
@@ -154,20 +209,17 @@ def main():
     # instrumented run (survivor fractions for the algorithmic-flop figure) on a 64k sample
     ns = min(B, 1 << 16)
     torch.cuda.synchronize()
-    counters = scene.check_batch_counted(q[:ns], flags[:ns], what)
+    counters = scene.check_batch_counted(q[:ns], flags[:ns], WHAT)
     flops_per_config, mix = algorithmic_flops_per_config(w, counters)
-    # what the large-batch path EXECUTES with its broadphase grid: candidates listed in the looked-up cells
-    # instead of every (shape, obstacle) pair; same SAT / exact counts.  256K configurations = 4 chunks.
+    # what the pipeline EXECUTES with its broadphase grid: candidates listed in the looked-up cells
+    # instead of every (shape, obstacle) pair.  256K configurations.
     nc = min(B, 1 << 18)
-    cand_per_config = None
-    if nc >= PIPE_MIN:
-        scene.check_batch_dev(q[:nc], flags[:nc], what | D.GH_PATH_PIPELINE | D.GH_COUNT_CANDIDATES, stream)
-        torch.cuda.synchronize()
-        st = scene.pipeline_last_stats()
-        n_self_pairs = mix["pairs_per_config"] - w.robot_keep.desc.n_shapes * w.obstacle_keep.desc.n_shapes
-        cand_per_config = st["candidates"] / nc + n_self_pairs
-    executed_flops = (mix["F_fk"] + 11.0 * cand_per_config + 220.0 * mix["sat_per_config"] + 600.0 * mix["exact_per_config"]
-                      if cand_per_config is not None else None)
+    scene.check_batch_dev(q[:nc], flags[:nc], WHAT | D.GH_COUNT_CANDIDATES, stream)
+    torch.cuda.synchronize()
+    st = scene.pipeline_last_stats()
+    n_self_pairs = mix["pairs_per_config"] - w.robot_keep.desc.n_shapes * w.obstacle_keep.desc.n_shapes
+    cand_per_config = st["candidates"] / nc + n_self_pairs
+    executed_flops = mix["F_fk"] + 11.0 * cand_per_config + 220.0 * mix["sat_per_config"] + 600.0 * mix["exact_per_config"]
 
     # With N > 1 the gather of step k's flag bytes (RCCL, its own stream) overlaps the check of step k+1:
     # two flag buffers, the collective asynchronous, waited for one step later and before the clock stops.
@@ -177,7 +229,7 @@ def main():
     def step(k):
         nonlocal pending
         f = fbuf[k % len(fbuf)]
-        scene.check_batch_dev(q, f, what, stream)
+        scene.check_batch_dev(q, f, WHAT, stream)
         if world > 1:
             if pending is not None:
                 pending.wait()
@@ -197,7 +249,7 @@ def main():
     for k in range(args.steps):
         f = fbuf[k % len(fbuf)]
         ev[k][0].record()
-        scene.check_batch_dev(q, f, what, stream)
+        scene.check_batch_dev(q, f, WHAT, stream)
         ev[k][1].record()
         if world > 1:
             if pending is not None:
@@ -242,21 +294,21 @@ def main():
                        "collectives": "all_gather(flags) per step, overlapped with the next step" if world > 1 else "none"},
             "roofline": {
                 "bound": "valu",
-                "kernel": ("k_sweep_grid + k_narrow1 + k_narrow2 + k_check(finalize), one launch of each per 1M-config chunk, "
-                           "chunks rotating over 4 streams from 3M configurations per call"
-                           if (B >= PIPE_MIN or int(w.obstacle_keep.desc.n_shapes) >= 32) else "k_check (fused)"),
+                "kernel": "k_sweep_n1 (FK + broadphase + stage 1 of the narrow phase; dominant) + k_narrow2 (exact stage) + "
+                          "k_check (hit words -> flag bytes), one launch of each per 1M-config chunk, chunks rotating over "
+                          "4 streams from 3M configurations per call",
                 "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak, "traffic": traffic,
-                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r01/v8_pipeline_traffic.json)",
+                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r02/pipeline_traffic.json)",
                 "algorithmic_bytes": bytes_per_config * B,
                 "kernel_ms": kernel_ms, "algorithmic_flops_per_config": flops_per_config, "mix": mix,
-                "executed": None if executed_flops is None else {
+                "executed": {
                     "broadphase_candidates_per_config": cand_per_config, "flops_per_config": executed_flops,
                     "TFLOPs": executed_flops * B / (kernel_ms * 1e-3) / 1e12,
                     "frac": executed_flops * B / (kernel_ms * 1e-3) / 1e12 / peak,
                     "note": "the broadphase grid replaces the L*O cull sweep that `achieved` prices (SURVEY 8d's "
                             "formula) by a cell lookup: `achieved`/`frac` say how fast the reference's pair set is "
-                            "decided, this entry how busy the vector units actually are"},
+                            "decided, this entry how busy the vector units are with arithmetic the formula counts"},
                 "hbm_algorithmic_GBps": bytes_per_config * B / (kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
                 "hbm_traffic_GBps": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
@@ -268,9 +320,18 @@ def main():
             "flag_rates": {"env": stats[0].item() / (B * world), "self": stats[1].item() / (B * world),
                            "limit": stats[2].item() / (B * world)},
         }
+        if world == 1 and not args.no_extras:
+            # the same scene in the other precision, and a free-space-dominant variant of it (the metric scene
+            # is dense: 59 % of random configurations collide, which lets the pipeline drop most of its
+            # undecided items): same code path, same batch, shorter runs
+            other = 64 if args.precision == 32 else 32
+            side_steps = max(2, args.steps // 2)
+            out["f64" if other == 64 else "f32"] = side_measurement(w, other, B, device, stream, side_steps, 1, 1234)
+            out["free_space"] = side_measurement(W.metric_workload_sparse(args.obstacles), args.precision, B, device, stream,
+                                                 side_steps, 1, 1234)
         if world == 1 and not args.no_cpu_baseline:
             k = 0 if args.no_parity else 256
-            out["cpu_baseline"] = cpu_baseline(w, args.precision, what, q[:k].cpu().numpy() if k else None,
+            out["cpu_baseline"] = cpu_baseline(w, args.precision, q[:k].cpu().numpy() if k else None,
                                                flags[:k].cpu().numpy() if k else None)
         print(json.dumps(out))
     if world > 1:

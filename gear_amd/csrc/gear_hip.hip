@@ -97,6 +97,7 @@ struct Knobs {
   bool zero_copy = true;                // GEAR_HIP_ZERO_COPY=0: host-buffer calls always copy (measuring aid)
   bool sweep_clds = true;               // GEAR_HIP_SWEEP_CLDS=0: cull table never in LDS
   int sweep_waves = 0;                  // GEAR_HIP_SWEEP_WAVES: wavefronts per sweep workgroup (0: chosen by LDS use)
+  int sweep_q = -1;                     // GEAR_HIP_SWEEP_Q: where the sweep keeps its batch row (0 memory, 2 LDS column; -1: chosen)
   bool n2_mlds = true;                  // GEAR_HIP_N2_MLDS=0: mesh table never in LDS
   bool n2_hist = false;                 // GEAR_HIP_N2_HIST: histogram of GJK iterations (profiling)
   bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
@@ -111,6 +112,7 @@ struct Knobs {
     k.zero_copy = num("GEAR_HIP_ZERO_COPY", 1) != 0;
     k.sweep_clds = num("GEAR_HIP_SWEEP_CLDS", 1) != 0;
     k.sweep_waves = (int)num("GEAR_HIP_SWEEP_WAVES", 0);
+    k.sweep_q = (int)num("GEAR_HIP_SWEEP_Q", -1);
     k.n2_mlds = num("GEAR_HIP_N2_MLDS", 1) != 0;
     k.n2_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;
     k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
@@ -306,6 +308,7 @@ constexpr size_t kLdsCu = 160 * 1024;
 // per wavefront the FK branch slots, the poses of the "earlier" self-pair shapes, the ring and the hit words
 struct SweepPlan {
   bool ok = false, clds = false;
+  int qmode = Q_MEM;
   unsigned table = 0, per_wave = 0, first = 0;
   int waves = 4;
   size_t lds() const { return table + rhot + (size_t)per_wave * waves; }
@@ -317,7 +320,8 @@ SweepPlan plan_sweep(const gh_scene* sc, const SceneDev<T>& S, bool do_env, bool
   SweepPlan best;
   const size_t slot_bytes = (size_t)S.n_slots * 7 * kWave * sizeof(T);
   const size_t first_bytes = do_self ? (size_t)S.n_first * 3 * kWave * sizeof(T) : 0;  // centres; the rotations wait in memory
-  const size_t per_wave = (slot_bytes + first_bytes + (size_t)kRing * 8 * sizeof(T) + 32 + 15) / 16 * 16;
+  const size_t q_bytes = (size_t)S.n_cols * kWave * sizeof(T);
+  const size_t base_wave = slot_bytes + first_bytes + (size_t)kRing * 8 * sizeof(T) + 32;
   const size_t rhot = ((size_t)S.n_shapes * 4 * sizeof(T) + 15) / 16 * 16;
   const size_t table = ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16;
   const size_t reg_waves = sizeof(T) == 4 ? 16 : 8;  // wavefronts per CU the registers allow (128 / 215 VGPRs)
@@ -328,20 +332,26 @@ SweepPlan plan_sweep(const gh_scene* sc, const SceneDev<T>& S, bool do_env, bool
   const bool want_clds = do_env && sc->knobs.sweep_clds && table <= 16 * 1024;
   size_t best_occ = 0;
   for (int clds = want_clds ? 1 : 0; clds >= 0 && !best.ok; clds--) {
-    for (int wv : {4, 2, 1}) {
-      if (sc->knobs.sweep_waves && wv != sc->knobs.sweep_waves) continue;
-      const size_t wg = (clds ? table : 0) + rhot + per_wave * wv;
-      if (wg > kLdsCu) continue;
-      const size_t occ = std::min(reg_waves, kLdsCu / wg * wv);
-      if (occ > best_occ) {  // ties: the larger workgroup (one table copy serves more wavefronts)
-        best_occ = occ;
-        best.ok = true;
-        best.clds = clds != 0;
-        best.table = clds ? (unsigned)table : 0u;
-        best.rhot = (unsigned)rhot;
-        best.per_wave = (unsigned)per_wave;
-        best.first = (unsigned)first_bytes;
-        best.waves = wv;
+    // the batch row moves into an LDS column when that does not cost a resident wavefront (first hit wins ties)
+    for (int qmode : {Q_LDS, Q_MEM}) {
+      if (sc->knobs.sweep_q >= 0 && qmode != sc->knobs.sweep_q) continue;
+      const size_t per_wave = (base_wave + (qmode == Q_LDS ? q_bytes : 0) + 15) / 16 * 16;
+      for (int wv : {4, 2, 1}) {
+        if (sc->knobs.sweep_waves && wv != sc->knobs.sweep_waves) continue;
+        const size_t wg = (clds ? table : 0) + rhot + per_wave * wv;
+        if (wg > kLdsCu) continue;
+        const size_t occ = std::min(reg_waves, kLdsCu / wg * wv);
+        if (occ > best_occ) {  // ties: the larger workgroup (one table copy serves more wavefronts)
+          best_occ = occ;
+          best.ok = true;
+          best.clds = clds != 0;
+          best.table = clds ? (unsigned)table : 0u;
+          best.rhot = (unsigned)rhot;
+          best.per_wave = (unsigned)per_wave;
+          best.first = (unsigned)first_bytes;
+          best.waves = wv;
+          best.qmode = qmode;
+        }
       }
     }
   }
@@ -416,10 +426,15 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     const unsigned n_sw = grid_for(cnt);  // sweep wavefronts
     {
       const dim3 grid((n_sw + sp.waves - 1) / sp.waves), block(kWave * sp.waves);
-      if (sp.clds)
-        hipLaunchKernelGGL((k_sweep_n1<T, true>), grid, block, sp.lds(), cs, S, qc, cnt, what, W, sp.table, sp.per_wave, sp.first, all_blk);
-      else
-        hipLaunchKernelGGL((k_sweep_n1<T, false>), grid, block, sp.lds(), cs, S, qc, cnt, what, W, sp.table, sp.per_wave, sp.first, all_blk);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, block, sp.lds(), cs, S, qc, cnt, what, W, sp.table, sp.per_wave, sp.first, all_blk);
+      };
+      switch ((sp.clds ? 4 : 0) + sp.qmode) {
+        case 0: go(k_sweep_n1<T, false, Q_MEM>); break;
+        case 2: go(k_sweep_n1<T, false, Q_LDS>); break;
+        case 4: go(k_sweep_n1<T, true, Q_MEM>); break;
+        default: go(k_sweep_n1<T, true, Q_LDS>); break;
+      }
     }
     {
       // the mesh pools (4-wide records) join the workgroup in LDS when they are at most 48 KB

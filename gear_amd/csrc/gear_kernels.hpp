@@ -99,7 +99,9 @@ template <class T> GD T joint_value(T qv, int direct, T mult, T off) { return di
 #pragma clang fp contract(fast)
 
 // k::Chain::set_joint_positions: true when every Range::is_valid holds
-template <class T> __device__ bool limits_ok(const SceneDev<T>& S, const Views<T>& V, const T* qrow) {
+// `qrow` below is anything that yields this lane's value of batch column c as qrow[c]: a pointer into the
+// batch, or one of the sweep's row holders (registers / an LDS column; gear_pipeline.hpp)
+template <class T, class Q> __device__ bool limits_ok(const SceneDev<T>& S, const Views<T>& V, const Q& qrow) {
   bool ok = true;
   for (int l = 0; l < S.n_limits; l++) {
     const GEAR_CAS LimitDev<T>* L = V.limits + l;
@@ -110,7 +112,7 @@ template <class T> __device__ bool limits_ok(const SceneDev<T>& S, const Views<T
 }
 
 // joint position of node k for this lane's configuration
-template <class T> __device__ __forceinline__ T node_position(const GEAR_CAS NodeDev<T>* nd, const T* qrow) {
+template <class T, class Q> __device__ __forceinline__ T node_position(const GEAR_CAS NodeDev<T>* nd, const Q& qrow) {
   T pos = nd->const_pos;
   int col = nd->col;
   if (col >= 0) pos = joint_value(qrow[col], nd->direct, nd->mult, nd->off);
@@ -119,8 +121,8 @@ template <class T> __device__ __forceinline__ T node_position(const GEAR_CAS Nod
 
 // world pose of node k given the walk state; updates `cur`.  SC: sin/cos of the half angle were
 // computed ahead of the walk and sit at sc[(2k) * 64 + lane], sc[(2k + 1) * 64 + lane].
-template <class T, bool SC = false>
-__device__ void node_world(const Views<T>& V, int k, const T* qrow, const PoseStore<T>& st, Pose<T>& cur,
+template <class T, bool SC = false, class Q = const T*>
+__device__ void node_world(const Views<T>& V, int k, const Q& qrow, const PoseStore<T>& st, Pose<T>& cur,
                            const T* sc = nullptr) {
   const GEAR_CAS NodeDev<T>* nd = V.nodes + k;
   Pose<T> parent = cur;

@@ -116,6 +116,17 @@ template <class T> GD ShapeRef<T> hot_ref(T hx, T hy, T hz, T kind) {
 
 template <class T> struct alignas(16) Cull4 { T x, y, z, r; };
 
+// Where the sweep keeps its lane's row of the batch.  Read straight from memory, every joint value costs the
+// walk a scalar load (which column?) and then a dependent vector load.  Q_LDS fetches the whole row with
+// independent loads when the wavefront starts and parks it in an LDS column: +5 % on env-only calls; it is
+// used when the column does not cost a resident wavefront (a register vector indexed by the uniform column
+// was measured too: the extra spills cost more than the loads).
+enum : int { Q_MEM = 0, Q_LDS = 2 };
+template <class T> struct QLds {
+  const T* col;  // this lane's column: element c at col[c * 64]
+  __device__ __forceinline__ T operator[](int c) const { return col[c * kWave]; }
+};
+
 // ---------------------------------------------------------------------------
 // k_sweep_n1
 //
@@ -142,7 +153,7 @@ constexpr int kSwThreads = 256;
 // rare paths, which costs less than the fourth wavefront hides), two in f64.
 template <class T> constexpr int sweep_occupancy() { return sizeof(T) == 4 ? 4 : 2; }
 
-template <class T, bool CLDS>
+template <class T, bool CLDS, int QMODE>
 __global__ void __launch_bounds__(kSwThreads, sweep_occupancy<T>())
 k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, PipeWs<T> W, unsigned table_bytes,
            unsigned per_wave_lds, unsigned first_bytes, int all_blk) {
@@ -158,7 +169,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   const size_t col = wave * kWave + lane;
   const bool live = wave_live && col < n;
   const size_t i = col < n ? col : n - 1;
-  const T* qrow = q + i * (size_t)S.n_cols;
+  const T* qmem = q + i * (size_t)S.n_cols;
 
   T* rhot = reinterpret_cast<T*>(gear_lds + table_bytes);  // [L][4] half extents, kind
   const unsigned rhot_bytes = ((unsigned)S.n_shapes * 4u * (unsigned)sizeof(T) + 15u) & ~15u;
@@ -169,6 +180,16 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   T* const fq_wave = W.fq + wave * (size_t)S.n_first * kWave * 4;    // [n_first][64][4] rotations (memory)
   T* const ring = reinterpret_cast<T*>(my_lds + slot_bytes + first_bytes);  // [kRing][8]
   unsigned* const hits = reinterpret_cast<unsigned*>(ring + (size_t)kRing * 8);  // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self
+  // this lane's row of the batch
+  QLds<T> qlds{reinterpret_cast<const T*>(hits + 8) + lane};  // Q_LDS: [n_cols][64] behind the hit words
+  if (QMODE == Q_LDS) {
+    T* w = reinterpret_cast<T*>(hits + 8) + lane;
+    for (int c = 0; c < S.n_cols; c++) w[c * kWave] = qmem[c];
+  }
+  auto qrow = [&]() -> decltype(auto) {
+    if constexpr (QMODE == Q_LDS) return (const QLds<T>&)qlds;
+    else return (const T* const&)qmem;
+  };
   {
     if (CLDS) {
       T* tab = reinterpret_cast<T*>(gear_lds);
@@ -189,7 +210,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   const Cull4<T>* __restrict__ ocull = CLDS ? reinterpret_cast<const Cull4<T>*>(gear_lds) : reinterpret_cast<const Cull4<T>*>(S.ocull);
   const unsigned sentinel = (unsigned)S.n_obs;
 
-  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
+  const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow());  // GH_CHECK_NO_LIMITS: geometry only
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
   const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
@@ -200,7 +221,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   unsigned xcount = 0;           // exact entries written by this wavefront, wave-uniform
   bool xover = false;
   bool env_done = false, self_done = false;  // this lane's configuration is already known to collide
-  unsigned long long ncand = 0;
+  unsigned long long ncand = 0;  // wave-uniform
   LaneCounters lc{0, 0, 0, 0};
 
   // ---- the narrow-phase site: decide up to 64 ring items, one per lane ----------------------------------
@@ -277,7 +298,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     const int target = sh->node;
     while (node < target) {
       node++;
-      node_world(V, node, qrow, slots, cur);
+      node_world<T, false>(V, node, qrow(), slots, cur);
     }
     const Pose<T> ws = pose_mul(cur, shape_pose<T>(sh));
     if (do_self) {
@@ -321,20 +342,12 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     if (__ballot(blk != 0) == 0) continue;  // no lane of the wavefront has a list to look at
     const T rho = sh->br;
     const unsigned code_base = ((unsigned)s << 6) | (unsigned)lane;
-    // the shape's oriented box: rotation matrix of its pose and half extents padded by the rounding of
-    // the transformed offset
+    // the shape's oriented box: half extents padded by the rounding of the transformed offset (a ball: the
+    // cube around it).  The offset is rotated with the pose quaternion itself: a rotation matrix would be
+    // nine more registers live across the drain below.
     const bool is_ball = sh->kind == SK_BALL;
     const T pad = T(1e-5) * (T(1) + rho);
     const T hbx = sh->half[0] + pad, hby = (is_ball ? sh->half[0] : sh->half[1]) + pad, hbz = (is_ball ? sh->half[0] : sh->half[2]) + pad;
-    T m00, m01, m02, m10, m11, m12, m20, m21, m22;
-    {
-      const Q4<T> r = ws.r;
-      const T ii = r.i * r.i, jj = r.j * r.j, kk = r.k * r.k, ij = r.i * r.j, ik = r.i * r.k, jk = r.j * r.k;
-      const T iw = r.i * r.w, jw = r.j * r.w, kw = r.k * r.w;
-      m00 = T(1) - T(2) * (jj + kk); m01 = T(2) * (ij - kw);        m02 = T(2) * (ik + jw);
-      m10 = T(2) * (ij + kw);        m11 = T(1) - T(2) * (ii + kk); m12 = T(2) * (jk - iw);
-      m20 = T(2) * (ik - jw);        m21 = T(2) * (jk + iw);        m22 = T(1) - T(2) * (ii + jj);
-    }
     bool more;
     do {
       const uint4 w = blocks[blk];
@@ -351,9 +364,9 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
         const T rr = rho + oc[j].r;
         h |= (dx * dx + dy * dy + dz * dz < rr * rr) ? (1u << j) : 0u;
       }
-      if (what & 0x8000u) {  // diagnostic count of the candidates
+      if (what & 0x8000u) {  // diagnostic count of the candidates (wave-uniform: no register per lane)
 #pragma unroll
-        for (int j = 0; j < 8; j++) ncand += id[j] != sentinel ? 1u : 0u;
+        for (int j = 0; j < 8; j++) ncand += (unsigned)__popcll(__ballot(id[j] != sentinel));
       }
       if (env_done || GEAR_DBG(what, 0x400u)) h = 0;  // the configuration already collides: its flags are an OR
       // one pass per hit of the busiest lane: second cull, then the survivors of the pass take ring slots
@@ -369,7 +382,10 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
         if (!GEAR_DBG(what, 0x200000u)) {
           const Cull4<T> c = ocull[idz];
           const T dx = c.x - ws.t.x, dy = c.y - ws.t.y, dz = c.z - ws.t.z;
-          const T px = m00 * dx + m10 * dy + m20 * dz, py = m01 * dx + m11 * dy + m21 * dz, pz = m02 * dx + m12 * dy + m22 * dz;  // R^T d
+          // R^T d = d + w t' + u x t' with u = -(i, j, k), t' = 2 u x d
+          const T ui = -ws.r.i, uj = -ws.r.j, uk = -ws.r.k;
+          const T tx = T(2) * (uj * dz - uk * dy), ty = T(2) * (uk * dx - ui * dz), tz = T(2) * (ui * dy - uj * dx);
+          const T px = dx + ws.r.w * tx + (uj * tz - uk * ty), py = dy + ws.r.w * ty + (uk * tx - ui * tz), pz = dz + ws.r.w * tz + (ui * ty - uj * tx);
           const T ex = t_max(t_abs(px) - hbx, T(0)), ey = t_max(t_abs(py) - hby, T(0)), ez = t_max(t_abs(pz) - hbz, T(0));
           pass = cand && (ex * ex + ey * ey + ez * ez < c.r * c.r);
         }
@@ -389,8 +405,8 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   while (count != 0) drain();
 
   if (what & 0x8000u) {
-    atomicAdd(&W.pc->candidates, ncand);
     if (lane == 0 && wave_live) {
+      atomicAdd(&W.pc->candidates, ncand);
       atomicAdd(&W.pc->exact, (unsigned long long)xcount);
       if (xover) atomicAdd(&W.pc->redo_waves, 1u);
     }
@@ -401,7 +417,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
     unsigned out = !ok ? 4u : ((env_hit ? 1u : 0u) | (self_hit ? 2u : 0u));
     if (xover) out |= kHitRedo;
-    if (live) W.hit[col] = out;
+    if (live) W.hit[wave * kWave + lane] = out;
     if (lane == 0 && wave_live) W.xcnt[wave] = xover ? 0u : xcount;
   }
 }

@@ -308,6 +308,13 @@ def metric_workload(n_obstacles: int = 256, seed: int = 0, margin: float = 0.01)
                     obstacle_field(n_obstacles, seed, ("box", "ball"), (0.6, 0.4)), margin, ARM7_SELF_PAIRS)
 
 
+def metric_workload_sparse(n_obstacles: int = 256, seed: int = 0, margin: float = 0.01) -> Workload:
+    """The metric scene's robot in a free-space-dominant field: the same obstacles spread over a 4.8 m cube
+    (13 % of random configurations collide with the environment instead of 59 %)."""
+    return Workload("arm7_vs_%d_box_ball_sparse" % n_obstacles, arm7_robot(),
+                    obstacle_field(n_obstacles, seed, ("box", "ball"), (0.6, 0.4), cube=4.8), margin, ARM7_SELF_PAIRS)
+
+
 def ur10_workload(n_obstacles: int = 256, seed: int = 1, margin: float = 0.01) -> Workload:
     """configs[2]: 6-DOF arm vs a box/cylinder field (cylinder obstacles: reference-undefined)."""
     return Workload("arm6_vs_%d_box_cyl" % n_obstacles, arm6_robot(),

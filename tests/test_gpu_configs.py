@@ -36,7 +36,7 @@ def test_config2_edge_validation_256_box_cyl(prec):
     # the field is dense (two thirds of random configurations collide): few whole edges stay free
     assert (first >= 0).sum() > 50 and (first < 0).sum() >= 20 and (first > 0).sum() > 50
     # oracle on a bounded subset of the edges
-    k = 40
+    k = 24
     sub_q, sub_off = q[:off[k]], off[:k + 1]
     wf, wb = ora.check_edges(sub_q, sub_off, D.GH_CHECK_ENV, bad_mask)
     allf, band = ora.check(sub_q, D.GH_CHECK_ENV, threads=16)

@@ -93,7 +93,7 @@ def test_flags_cylinder_obstacles(prec):
 
 @pytest.mark.parametrize("prec", [32, 64])
 def test_flags_4096_obstacles(prec):
-    _check_flags("flags_4096_obstacles", W.sawyer_workload(4096), prec, 512, seed=5)
+    _check_flags("flags_4096_obstacles", W.sawyer_workload(4096), prec, 128, seed=5)   # the 640-configuration sample: test_gpu_configs.py
 
 
 @pytest.mark.parametrize("prec", [32, 64])
