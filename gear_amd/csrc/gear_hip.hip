@@ -100,6 +100,7 @@ struct Knobs {
   int sweep_q = -1;                     // GEAR_HIP_SWEEP_Q: where the sweep keeps its batch row (0 memory, 2 LDS column; -1: chosen)
   bool n2_mlds = true;                  // GEAR_HIP_N2_MLDS=0: mesh table never in LDS
   bool n2_hist = false;                 // GEAR_HIP_N2_HIST: histogram of GJK iterations (profiling)
+  int n2_tile = 16;                     // GEAR_HIP_N2_TILE: sweep wavefronts per exact-stage workgroup (8, 16, 32)
   bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
   static Knobs from_env() {
     Knobs k;
@@ -115,6 +116,7 @@ struct Knobs {
     k.sweep_q = (int)num("GEAR_HIP_SWEEP_Q", -1);
     k.n2_mlds = num("GEAR_HIP_N2_MLDS", 1) != 0;
     k.n2_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;
+    k.n2_tile = (int)num("GEAR_HIP_N2_TILE", 16);
     k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
     return k;
   }
@@ -439,9 +441,12 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     {
       // the mesh pools (4-wide records) join the workgroup in LDS when they are at most 48 KB
       const size_t mesh_bytes = (size_t)(S.n_verts + S.n_planes) * 4 * sizeof(T);
-      const dim3 grid((n_sw + kN2Tile - 1) / kN2Tile), block(kN2Threads);
+      const int tile = sc->knobs.n2_tile == 8 ? 8 : sc->knobs.n2_tile == 32 ? 32 : 16;
+      const dim3 grid((n_sw + tile - 1) / tile), block(kN2Threads);
+      const bool mlds = sc->knobs.n2_mlds && mesh_bytes > 0 && mesh_bytes <= 48 * 1024;
+      auto go = [&](auto kern, size_t lds) { hipLaunchKernelGGL(kern, grid, block, lds, cs, S, what, W, n_sw); };
       if (sc->knobs.n2_hist) {
-        hipLaunchKernelGGL((k_narrow2<T, false, true>), grid, block, 0, cs, S, what, W, n_sw);
+        go(k_narrow2<T, false, true, 16>, 0);
         GH_HIP(hipStreamSynchronize(cs));
         PipeCounters h;
         GH_HIP(hipMemcpy(&h, W.pc, sizeof(h), hipMemcpyDeviceToHost));
@@ -450,10 +455,15 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
           for (int k = 0; k < 48; k++) fprintf(stderr, " %u", h.hist[r][k]);
           fprintf(stderr, "\n");
         }
-      } else if (sc->knobs.n2_mlds && mesh_bytes > 0 && mesh_bytes <= 48 * 1024)
-        hipLaunchKernelGGL((k_narrow2<T, true>), grid, block, mesh_bytes, cs, S, what, W, n_sw);
-      else
-        hipLaunchKernelGGL((k_narrow2<T, false>), grid, block, 0, cs, S, what, W, n_sw);
+      } else if (mlds) {
+        if (tile == 8) go(k_narrow2<T, true, false, 8>, mesh_bytes);
+        else if (tile == 32) go(k_narrow2<T, true, false, 32>, mesh_bytes);
+        else go(k_narrow2<T, true, false, 16>, mesh_bytes);
+      } else {
+        if (tile == 8) go(k_narrow2<T, false, false, 8>, 0);
+        else if (tile == 32) go(k_narrow2<T, false, false, 32>, 0);
+        else go(k_narrow2<T, false, false, 16>, 0);
+      }
     }
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());

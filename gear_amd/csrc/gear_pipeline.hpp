@@ -433,10 +433,10 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
 // access per vertex or plane.
 // ---------------------------------------------------------------------------
 constexpr int kN2Threads = 256;
-constexpr int kN2Tile = 32;      // sweep wavefronts per workgroup
 constexpr int kN2Window = 4096;  // entries binned at a time
 
-template <class T, bool MLDS, bool HIST = false>
+// kN2Tile: sweep wavefronts per workgroup (a power of two)
+template <class T, bool MLDS, bool HIST = false, int kN2Tile = 32>
 __global__ void __launch_bounds__(kN2Threads)
 k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned n_sweep_waves) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
