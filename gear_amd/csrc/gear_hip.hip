@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gear_hip.h"
@@ -144,6 +145,7 @@ struct gh_scene {
   bool has_mesh = false;
   Knobs knobs;
   CountersDev* counters = nullptr;
+  std::vector<gh_scene*> parts;  // gh_scene_create_multi: one scene per listed device; this object only routes
   size_t elem() const { return precision == 32 ? 4 : 8; }
 };
 
@@ -529,6 +531,27 @@ struct Guard {
   }
 };
 
+// ---- device groups (gh_scene_create_multi) --------------------------------------------------------
+// The batch shards naturally: configurations are independent and an edge needs only its own samples.  A
+// group gives every listed device a contiguous share (whole edges), runs the shares concurrently — one
+// host thread per device, each through the ordinary single-device entry point with its own stream,
+// staging buffers and workspace — and the results land in the caller's buffers.  No collective: the
+// scene was replicated at creation.
+template <class F>
+int run_parts(gh_scene* sc, size_t n_parts, F&& body) {  // body(k) -> status; errors keep their text
+  std::vector<int> rc(n_parts, GH_OK);
+  std::vector<std::string> msg(n_parts);
+  std::vector<std::thread> pool;
+  for (size_t k = 1; k < n_parts; k++)
+    pool.emplace_back([&, k] { rc[k] = body(k); if (rc[k]) msg[k] = g_last_error; });
+  rc[0] = body(0);
+  if (rc[0]) msg[0] = g_last_error;
+  for (auto& t : pool) t.join();
+  for (size_t k = 0; k < n_parts; k++)
+    if (rc[k]) return fail(rc[k], "device " + std::to_string(sc->parts[k]->device) + ": " + msg[k]);
+  return GH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -583,8 +606,41 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
   return GH_OK;
 }
 
+int gh_scene_create_multi(const gh_robot_desc* robot, const gh_obstacle_desc* obstacles, double margin, int precision,
+                          const int* devices, int n_devices, gh_scene** out) {
+  if (!out) return fail(GH_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (!devices || n_devices < 1 || n_devices > 64) return fail(GH_ERR_INVALID, "device list must hold 1..64 entries");
+  gh_scene* grp = new (std::nothrow) gh_scene;
+  if (!grp) return fail(GH_ERR_INVALID, "out of host memory");
+  for (int k = 0; k < n_devices; k++) {
+    gh_scene* part = nullptr;
+    int rc = gh_scene_create(robot, obstacles, margin, precision, devices[k], &part);
+    if (rc != GH_OK) {
+      std::string keep = g_last_error;
+      for (gh_scene* p : grp->parts) gh_scene_destroy(p);
+      delete grp;
+      g_last_error = keep;
+      return rc;
+    }
+    grp->parts.push_back(part);
+  }
+  const gh_scene* p0 = grp->parts[0];
+  grp->precision = p0->precision; grp->device = p0->device; grp->margin = p0->margin;
+  grp->D = p0->D; grp->N = p0->N; grp->L = p0->L; grp->O = p0->O; grp->P = p0->P;
+  *out = grp;
+  return GH_OK;
+}
+
+int gh_scene_device_count(const gh_scene* sc) { return sc ? (sc->parts.empty() ? 1 : (int)sc->parts.size()) : GH_ERR_INVALID; }
+
 void gh_scene_destroy(gh_scene* sc) {
   if (!sc) return;
+  if (!sc->parts.empty()) {
+    for (gh_scene* p : sc->parts) gh_scene_destroy(p);
+    delete sc;
+    return;
+  }
   {
     Guard g(sc);
     if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
@@ -611,6 +667,7 @@ int gh_scene_device(const gh_scene* sc) { return sc ? sc->device : GH_ERR_INVALI
 int gh_link_mask_words(const gh_scene* sc) { return sc ? (sc->N + 63) / 64 : GH_ERR_INVALID; }
 
 int gh_check_batch_dev(gh_scene* sc, const void* q_dev, size_t n, uint32_t what, uint8_t* flags_dev, void* stream) {
+  if (sc && !sc->parts.empty()) return fail(GH_ERR_INVALID, "device-pointer entry points take a single-device scene: use the parts of a group one by one, or the host-buffer entry points");
   if (!sc || (n && (!q_dev || !flags_dev))) return fail(GH_ERR_INVALID, "null argument");
   if (n && sc->D == 0) return fail(GH_ERR_DOF_MISMATCH, "scene has no batch columns");
   Guard g(sc);
@@ -619,6 +676,15 @@ int gh_check_batch_dev(gh_scene* sc, const void* q_dev, size_t n, uint32_t what,
 }
 
 int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags) {
+  if (sc && !sc->parts.empty()) {
+    if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
+    const size_t G = std::min<size_t>(sc->parts.size(), std::max<size_t>(n, 1));
+    const size_t row = (size_t)sc->D * sc->elem();
+    return run_parts(sc, G, [&](size_t k) {
+      const size_t lo = n * k / G, hi = n * (k + 1) / G;
+      return gh_check_batch(sc->parts[k], (const char*)q + lo * row, hi - lo, what, flags + lo);
+    });
+  }
   if (!sc || (n && (!q || !flags))) return fail(GH_ERR_INVALID, "null argument");
   if (n == 0) return GH_OK;
   Guard g(sc);
@@ -643,6 +709,7 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
 
 int gh_check_batch_counted(gh_scene* sc, const void* q_dev, size_t n, uint32_t what, uint8_t* flags_dev,
                            gh_counters* out) {
+  if (sc && !sc->parts.empty()) return fail(GH_ERR_INVALID, "device-pointer entry points take a single-device scene");
   if (!sc || !out || (n && (!q_dev || !flags_dev))) return fail(GH_ERR_INVALID, "null argument");
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
@@ -659,6 +726,7 @@ int gh_check_batch_counted(gh_scene* sc, const void* q_dev, size_t n, uint32_t w
 }
 
 int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
+  if (sc && !sc->parts.empty()) sc = sc->parts[0];
   if (!sc || !out) return fail(GH_ERR_INVALID, "null argument");
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
@@ -694,6 +762,7 @@ static int check_edges_locked(gh_scene* sc, const void* q_dev, const uint32_t* e
 
 int gh_check_edges_dev(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges, size_t n_samples,
                        uint32_t what, uint8_t bad_mask, uint8_t* flags_dev, int32_t* first_bad_dev, void* stream) {
+  if (sc && !sc->parts.empty()) return fail(GH_ERR_INVALID, "device-pointer entry points take a single-device scene");
   if (!sc || (n_edges && (!edge_off_dev || !first_bad_dev)) || (n_samples && (!q_dev || !flags_dev)))
     return fail(GH_ERR_INVALID, "null argument");
   Guard g(sc);
@@ -704,6 +773,31 @@ int gh_check_edges_dev(gh_scene* sc, const void* q_dev, const uint32_t* edge_off
 
 int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t n_edges, uint32_t what,
                    uint8_t bad_mask, uint8_t* flags, int32_t* first_bad) {
+  if (sc && !sc->parts.empty()) {
+    if (!edge_off || (n_edges && !first_bad)) return fail(GH_ERR_INVALID, "null argument");
+    if (n_edges == 0) return GH_OK;
+    if (edge_off[0] != 0) return fail(GH_ERR_INVALID, "edge_off[0] must be 0");
+    for (size_t e = 0; e < n_edges; e++)
+      if (edge_off[e + 1] < edge_off[e]) return fail(GH_ERR_INVALID, "edge_off must be non-decreasing");
+    const size_t n = edge_off[n_edges];
+    if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
+    // contiguous shares of whole edges, balanced by samples: share k starts at the first edge whose
+    // first sample is at or beyond n * k / G
+    const size_t G = std::min<size_t>(sc->parts.size(), n_edges);
+    std::vector<size_t> cut(G + 1, n_edges);
+    cut[0] = 0;
+    for (size_t k = 1; k < G; k++)
+      cut[k] = std::max<size_t>(cut[k - 1], (size_t)(std::lower_bound(edge_off, edge_off + n_edges, (uint32_t)(n * k / G)) - edge_off));
+    const size_t row = (size_t)sc->D * sc->elem();
+    return run_parts(sc, G, [&](size_t k) -> int {
+      const size_t e0 = cut[k], e1 = cut[k + 1];
+      if (e0 == e1) return GH_OK;
+      std::vector<uint32_t> off(e1 - e0 + 1);
+      for (size_t e = e0; e <= e1; e++) off[e - e0] = edge_off[e] - edge_off[e0];
+      return gh_check_edges(sc->parts[k], (const char*)q + (size_t)edge_off[e0] * row, off.data(), e1 - e0, what, bad_mask,
+                            flags + edge_off[e0], first_bad + e0);
+    });
+  }
   if (!sc || !edge_off || (n_edges && !first_bad)) return fail(GH_ERR_INVALID, "null argument");
   if (n_edges == 0) return GH_OK;
   for (size_t e = 0; e < n_edges; e++)
@@ -746,6 +840,7 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
 }
 
 int gh_fk_batch_dev(gh_scene* sc, const void* q_dev, size_t n, void* poses_dev, void* stream) {
+  if (sc && !sc->parts.empty()) return fail(GH_ERR_INVALID, "device-pointer entry points take a single-device scene");
   if (!sc || (n && (!q_dev || !poses_dev))) return fail(GH_ERR_INVALID, "null argument");
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
@@ -753,6 +848,15 @@ int gh_fk_batch_dev(gh_scene* sc, const void* q_dev, size_t n, void* poses_dev, 
 }
 
 int gh_fk_batch(gh_scene* sc, const void* q, size_t n, void* poses) {
+  if (sc && !sc->parts.empty()) {
+    if (n && (!q || !poses)) return fail(GH_ERR_INVALID, "null argument");
+    const size_t G = std::min<size_t>(sc->parts.size(), std::max<size_t>(n, 1));
+    const size_t row = (size_t)sc->D * sc->elem(), prow = (size_t)sc->N * 7 * sc->elem();
+    return run_parts(sc, G, [&](size_t k) {
+      const size_t lo = n * k / G, hi = n * (k + 1) / G;
+      return gh_fk_batch(sc->parts[k], (const char*)q + lo * row, hi - lo, (char*)poses + lo * prow);
+    });
+  }
   if (!sc || (n && (!q || !poses))) return fail(GH_ERR_INVALID, "null argument");
   if (n == 0) return GH_OK;
   Guard g(sc);
@@ -768,6 +872,7 @@ int gh_fk_batch(gh_scene* sc, const void* q, size_t n, void* poses) {
 }
 
 int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t* link_mask) {
+  if (sc && !sc->parts.empty()) sc = sc->parts[0];  // a diagnostic: one device serves it
   if (!sc || (n && (!q || !link_mask))) return fail(GH_ERR_INVALID, "null argument");
   if (n == 0 || sc->O == 0) return GH_OK;
   if (sc->N > 128) return fail(GH_ERR_TOO_LARGE, "gh_link_hits supports at most 128 nodes");
@@ -798,6 +903,7 @@ int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t*
 }
 
 int gh_self_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t* pair_mask) {
+  if (sc && !sc->parts.empty()) sc = sc->parts[0];
   if (!sc || (n && (!q || !pair_mask))) return fail(GH_ERR_INVALID, "null argument");
   if (n == 0 || sc->P == 0) return GH_OK;
   Guard g(sc);

@@ -17,7 +17,7 @@ from .build import LIB_PATH
 _LIB = None
 
 SYMBOLS = [
-    "gh_scene_create", "gh_scene_destroy", "gh_scene_dof", "gh_scene_nodes", "gh_scene_precision",
+    "gh_scene_create", "gh_scene_create_multi", "gh_scene_device_count", "gh_scene_destroy", "gh_scene_dof", "gh_scene_nodes", "gh_scene_precision",
     "gh_scene_device", "gh_check_batch", "gh_check_batch_dev", "gh_check_edges", "gh_check_edges_dev",
     "gh_fk_batch", "gh_fk_batch_dev", "gh_link_hits", "gh_link_mask_words", "gh_self_hits",
     "gh_check_batch_counted", "gh_pipeline_last_stats", "gh_last_error", "gh_version",
@@ -39,6 +39,8 @@ def lib():
         L = C.CDLL(path)
         vp, sz, u32, u8 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8
         L.gh_scene_create.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int, C.POINTER(vp)]
+        L.gh_scene_create_multi.argtypes = [vp, vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.gh_scene_device_count.argtypes = [vp]
         L.gh_scene_destroy.argtypes = [vp]
         L.gh_scene_destroy.restype = None
         for name in ("gh_scene_dof", "gh_scene_nodes", "gh_scene_precision", "gh_scene_device", "gh_link_mask_words"):
@@ -71,11 +73,18 @@ def _ptr(a):
 class Scene:
     """An immutable robot + obstacle scene resident in HBM (gh_scene)."""
 
-    def __init__(self, robot_keep, obstacle_keep, margin: float, precision: int = 32, device: int = 0):
+    def __init__(self, robot_keep, obstacle_keep, margin: float, precision: int = 32, device: int = 0, devices=None):
+        """devices: a list of device indices -> gh_scene_create_multi (the batch is sharded over them)."""
         self._keep = (robot_keep, obstacle_keep)
         self.h = C.c_void_p()
-        _check(lib().gh_scene_create(C.addressof(robot_keep.desc), C.addressof(obstacle_keep.desc), float(margin),
-                                     int(precision), int(device), C.byref(self.h)))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().gh_scene_create_multi(C.addressof(robot_keep.desc), C.addressof(obstacle_keep.desc), float(margin),
+                                               int(precision), arr, len(devices), C.byref(self.h)))
+            device = devices[0]
+        else:
+            _check(lib().gh_scene_create(C.addressof(robot_keep.desc), C.addressof(obstacle_keep.desc), float(margin),
+                                         int(precision), int(device), C.byref(self.h)))
         self.precision = precision
         self.dtype = np.float32 if precision == 32 else np.float64
         self.device = device

@@ -168,6 +168,18 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
                     double margin, int precision, int device, gh_scene** out);
 void gh_scene_destroy(gh_scene* scene);
 
+/* The same scene on several devices of one node (no counterpart in the reference, which is single-threaded:
+ * this is the sharding SURVEY.md 8(e) describes, inside the library).  The scene tables are replicated on
+ * every listed device; gh_check_batch, gh_check_edges and gh_fk_batch then give each device a contiguous
+ * share of the batch (whole edges; balanced by samples), run the shares concurrently — one host thread,
+ * stream, staging area and workspace per device — and write the results into the caller's buffers.  No
+ * collective is involved.  The diagnostics (gh_link_hits, gh_self_hits, gh_pipeline_last_stats) are
+ * served by the first device; the `_dev` entry points and gh_check_batch_counted take device pointers and
+ * therefore a single-device scene.  A device may be listed more than once (each entry is a share). */
+int gh_scene_create_multi(const gh_robot_desc* robot, const gh_obstacle_desc* obstacles, double margin,
+                          int precision, const int* devices, int n_devices, gh_scene** out);
+int gh_scene_device_count(const gh_scene* scene); /* 1 for gh_scene_create */
+
 int gh_scene_dof(const gh_scene* scene);       /* D  */
 int gh_scene_nodes(const gh_scene* scene);     /* N  */
 int gh_scene_precision(const gh_scene* scene); /* 32|64 */
