@@ -120,6 +120,8 @@ def shape_from_urdf_geometry(g: U.Geometry, base_dir: Optional[str]) -> Optional
         if not os.path.exists(path):
             return None  # urdf.rs:60-63: error!(..) and None
         verts, tris = U.load_obj_mesh(path, g.scale)
+        if not verts or not tris:
+            return None  # urdf.rs:66-69: load_mesh failed, error!(..) and None
         return ShapeSpec(GH_SHAPE_MESH, (0.0, 0.0, 0.0), vertices=verts, triangles=tris)
     return None
 

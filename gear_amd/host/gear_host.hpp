@@ -412,7 +412,9 @@ struct ShapeSpec {  // one (ShapeHandle, Isometry3)
 };
 
 // Wavefront-OBJ triangles, per-axis scale, sub-meshes merged: stands in for the assimp import of
-// src/collision/mesh.rs:39-69 (triangles only; scale applied per vertex)
+// src/collision/mesh.rs:39-69 (triangles only: faces of any other size are dropped, :55-65; assimp holds
+// f32 coordinates and the scale is applied in f64, `v.x as f64 * scale[0]`, :49-53; the indices of every
+// sub-mesh continue after the previous one's vertices, :66)
 inline bool load_obj_mesh(const std::string& path, const double scale[3], ShapeSpec& out) {
   std::ifstream f(path);
   if (!f) return false;
@@ -423,7 +425,7 @@ inline bool load_obj_mesh(const std::string& path, const double scale[3], ShapeS
     if (!(is >> tok)) continue;
     if (tok == "v") {
       double x, y, z;
-      if (is >> x >> y >> z) { out.vertices.push_back(x * scale[0]); out.vertices.push_back(y * scale[1]); out.vertices.push_back(z * scale[2]); }
+      if (is >> x >> y >> z) { out.vertices.push_back((double)(float)x * scale[0]); out.vertices.push_back((double)(float)y * scale[1]); out.vertices.push_back((double)(float)z * scale[2]); }
     } else if (tok == "f") {
       std::vector<int> idx;
       while (is >> tok) {

@@ -198,7 +198,15 @@ const char* gp_describe(gp_planner* p) {
         const ShapeSpec& sp = it->second[s];
         o << (s ? "," : "") << "{\"kind\":" << sp.kind << ",\"params\":[" << sp.params[0] << "," << sp.params[1] << "," << sp.params[2]
           << "],\"t\":[" << sp.t[0] << "," << sp.t[1] << "," << sp.t[2] << "],\"q\":[" << sp.q[0] << "," << sp.q[1] << "," << sp.q[2] << ","
-          << sp.q[3] << "]}";
+          << sp.q[3] << "]";
+        if (sp.kind == GH_SHAPE_MESH) {  // the flattened mesh: what load_obj_mesh made of the file
+          o << ",\"vertices\":[";
+          for (size_t v = 0; v < sp.vertices.size(); v++) o << (v ? "," : "") << sp.vertices[v];
+          o << "],\"triangles\":[";
+          for (size_t v = 0; v < sp.triangles.size(); v++) o << (v ? "," : "") << sp.triangles[v];
+          o << "]";
+        }
+        o << "}";
       }
     o << "]}";
   }

@@ -271,8 +271,11 @@ def link_to_joint_map(robot: UrdfRobot) -> Dict[str, str]:
 
 
 def load_obj_mesh(path: str, scale=(1.0, 1.0, 1.0)):
-    """Minimal Wavefront-OBJ reader standing in for src/collision/mesh.rs:39-69
-    (assimp): triangles only, per-axis scale, all sub-meshes merged."""
+    """Minimal Wavefront-OBJ reader standing in for src/collision/mesh.rs:39-69 (assimp): triangles only
+    (faces of another size are dropped, :55-65), all sub-meshes merged (:66), coordinates held as f32 by
+    assimp and scaled per axis in f64 (`v.x as f64 * scale[0]`, :49-53)."""
+    import numpy as np
+    f32 = lambda t: float(np.float32(float(t)))
     verts, tris = [], []
     with open(path, "r") as fh:
         for line in fh:
@@ -280,7 +283,7 @@ def load_obj_mesh(path: str, scale=(1.0, 1.0, 1.0)):
             if not p:
                 continue
             if p[0] == "v":
-                verts.append((float(p[1]) * scale[0], float(p[2]) * scale[1], float(p[3]) * scale[2]))
+                verts.append((f32(p[1]) * scale[0], f32(p[2]) * scale[1], f32(p[3]) * scale[2]))
             elif p[0] == "f":
                 idx = [int(tok.split("/")[0]) for tok in p[1:]]
                 if len(idx) == 3:  # mesh.rs keeps triangles only
