@@ -89,6 +89,15 @@ constexpr size_t kZeroCopyMax = 4096;  // configurations (and edges) up to which
 
 constexpr int kMaxSets = 4;
 
+// ---- gh_check_batch_noalloc: workspace that nobody allocates --------------------------------------
+// One array per GPU, part of the code object: it exists from the moment the library's code is loaded on a
+// device until the process ends.  `scratch` is the host-side stand-in of the symbol, NOT a device address:
+// host code only ever uses the per-device address that hipGetSymbolAddress returned (scratch_on_device).
+constexpr size_t kScratchBytes = size_t(64) << 20;
+constexpr size_t kNoAllocMaxConfigs = size_t(1) << 16;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
 // Tuning and test hooks.  Read from the environment ONCE, when a scene is created; no entry point looks
 // at the environment afterwards.
 struct Knobs {
@@ -122,6 +131,37 @@ struct Knobs {
     return k;
   }
 };
+
+namespace {
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};  // device k's copy of `scratch`, as device k addresses it
+
+// Address of the CURRENT device's copy of the array (looked up once per device; the caller has made
+// `device` current).
+int scratch_on_device(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) return fail(GH_ERR_INVALID, "device index beyond the no-allocation workspace table");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    GH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(GH_ERR_HIP, "hipGetSymbolAddress returned no address for the workspace array");
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return GH_OK;
+}
+
+// A caller-less bump allocator over a fixed region (the no-allocation entry point's workspace)
+struct Carve {
+  char* base = nullptr;
+  size_t bytes = 0, used = 0;
+  void* take(size_t need) {  // 256-byte aligned; nullptr when the region is exhausted (used keeps counting)
+    const size_t at = (used + 255) / 256 * 256;
+    used = at + need;
+    return used <= bytes ? base + at : nullptr;
+  }
+};
+}  // namespace
 
 struct gh_scene {
   int precision = 32, device = 0;
@@ -243,7 +283,7 @@ StorePlan plan_store(const gh_scene* sc, bool shape_poses) {
 // Runs `launch(offset, count, gstore, gstride)` over [0, n), in chunks when the
 // pose columns live in a global workspace.
 template <class F>
-int for_chunks(gh_scene* sc, size_t n, const StorePlan& plan, F&& launch) {
+int for_chunks(gh_scene* sc, size_t n, const StorePlan& plan, F&& launch, Carve* fixed = nullptr) {
   if (n == 0) return GH_OK;
   if (!plan.global) {
     launch((size_t)0, n, nullptr, (size_t)0);
@@ -252,10 +292,18 @@ int for_chunks(gh_scene* sc, size_t n, const StorePlan& plan, F&& launch) {
   }
   size_t chunk = std::min(n, kChunk);
   size_t stride = (chunk + kWave - 1) / kWave * kWave;
-  int rc = sc->store.ensure(plan.slots * 7 * stride * sc->elem());
-  if (rc) return rc;
+  void* store;
+  if (fixed) {
+    store = fixed->take(plan.slots * 7 * stride * sc->elem());
+    if (!store) return fail(GH_ERR_TOO_LARGE, "this scene's pose columns for " + std::to_string(n) + " configurations need " +
+                            std::to_string(fixed->used) + " bytes; the no-allocation workspace holds " + std::to_string(fixed->bytes));
+  } else {
+    int rc = sc->store.ensure(plan.slots * 7 * stride * sc->elem());
+    if (rc) return rc;
+    store = sc->store.p;
+  }
   for (size_t off = 0; off < n; off += chunk) {
-    launch(off, std::min(chunk, n - off), sc->store.p, stride);
+    launch(off, std::min(chunk, n - off), store, stride);
     GH_HIP(hipGetLastError());
   }
   return GH_OK;
@@ -364,7 +412,7 @@ SweepPlan plan_sweep(const gh_scene* sc, const SceneDev<T>& S, bool do_env, bool
 
 template <class T>
 int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags,
-                 hipStream_t st) {
+                 hipStream_t st, Carve* fixed = nullptr) {
   const bool do_self = (what & 2u) && S.n_spairs > 0;
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const SweepPlan sp = plan_sweep<T>(sc, S, do_env, do_self);
@@ -383,11 +431,36 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   // batches of at least kMultiStreamMin configurations and two chunks rotate over several streams.
   int n_sets = (!plan.global && n >= kMultiStreamMin) ? sc->knobs.pipe_streams : 1;
   n_sets = (int)std::min<size_t>(n_sets, (n + chunk - 1) / chunk);
+  if (fixed) n_sets = 1;
   const bool two = n_sets > 1;
   const size_t waves = chunk / kWave;
   PipeWs<T> Ws[kMaxSets];
   int rc;
-  for (int k = 0; k < n_sets; k++) {
+  void* gs = nullptr;
+  size_t gstride = 0;
+  if (fixed) {  // the same arrays, cut from the fixed region: nothing is allocated, nothing of the scene's is touched
+    PipeWs<T>& W = Ws[0];
+    W = PipeWs<T>{};
+    W.capw = capw;
+    W.hit = (unsigned*)fixed->take(chunk * 4);
+    W.xcnt = (unsigned*)fixed->take(waves * 4);
+    W.xkey = (uint2*)fixed->take(waves * capw * 8);
+    W.xpose_a = (T*)fixed->take(waves * capw * 8 * sizeof(T));
+    W.xpose_b = do_self ? (T*)fixed->take(waves * capw * 8 * sizeof(T)) : nullptr;
+    W.fq = do_self ? (T*)fixed->take(std::max<size_t>(waves * (size_t)S.n_first * kWave * 4 * sizeof(T), 16)) : nullptr;
+    W.pc = (PipeCounters*)fixed->take(sizeof(PipeCounters));
+    if (plan.global) {
+      gs = fixed->take(plan.slots * 7 * chunk * sizeof(T));
+      gstride = chunk;
+    }
+    if (fixed->used > fixed->bytes) {
+      const size_t per_wave = fixed->used / waves + 1;
+      return fail(GH_ERR_TOO_LARGE, "the workspace of this scene for " + std::to_string(n) + " configurations is " +
+                  std::to_string(fixed->used) + " bytes; the no-allocation workspace holds " + std::to_string(fixed->bytes) +
+                  " (about " + std::to_string(fixed->bytes / per_wave * kWave) + " configurations of this scene per call)");
+    }
+  }
+  for (int k = 0; k < n_sets && !fixed; k++) {
     PipeWs<T>& W = Ws[k];
     gh_scene::PipeBufs& b = sc->pw[k];
     W = PipeWs<T>{};
@@ -406,10 +479,8 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     W.fq = do_self ? (T*)b.fq.p : nullptr;
     W.pc = (PipeCounters*)b.pc.p;
   }
-  sc->last_sets = n_sets;
-  void* gs = nullptr;
-  size_t gstride = 0;
-  if (plan.global) {
+  if (!fixed) sc->last_sets = n_sets;
+  if (plan.global && !fixed) {
     if ((rc = sc->store.ensure(plan.slots * 7 * chunk * sizeof(T)))) return rc;
     gs = sc->store.p;
     gstride = chunk;
@@ -479,7 +550,8 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   return GH_OK;
 }
 
-int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted) {
+int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted,
+              Carve* fixed = nullptr) {
 #ifndef GEAR_HIP_ABLATE
   what &= kWhatPublic;  // undeclared bits never reach a kernel (the ablation build of tools/ keeps them)
 #endif
@@ -492,8 +564,8 @@ int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* fla
   }
   if (pipe_ok) {
     if (n == 0) return GH_OK;
-    return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st)
-                               : pipeline_dev<double>(sc, sc->s64, (const double*)q, n, what, flags, st);
+    return sc->precision == 32 ? pipeline_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st, fixed)
+                               : pipeline_dev<double>(sc, sc->s64, (const double*)q, n, what, flags, st, fixed);
   }
   StorePlan plan = plan_store(sc, true);  // the batched kernel keeps every shape pose in the lane's column
   return for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
@@ -501,7 +573,7 @@ int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* fla
       launch_check<float>(sc, sc->s32, (const float*)q + off * sc->D, cnt, what, flags + off, st, counted, plan, gs, gstride);
     else
       launch_check<double>(sc, sc->s64, (const double*)q + off * sc->D, cnt, what, flags + off, st, counted, plan, gs, gstride);
-  });
+  }, fixed);
 }
 
 int fk_dev(gh_scene* sc, const void* q, size_t n, void* poses, hipStream_t st) {
@@ -583,6 +655,8 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
                            : build_and_upload<double>(sc, *robot, *obstacles, margin, sc->s64);
       if (rc == GH_OK && hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(GH_ERR_HIP, "hipStreamCreate failed");
+      void* ws = nullptr;  // this device's copy of the no-allocation workspace: its address is looked up here, once
+      if (rc == GH_OK) rc = scratch_on_device(device, &ws);
       if (rc == GH_OK && hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming) != hipSuccess)
         rc = fail(GH_ERR_HIP, "hipEventCreate failed");
       for (int k = 1; k < kMaxSets && rc == GH_OK; k++)
@@ -673,6 +747,25 @@ int gh_check_batch_dev(gh_scene* sc, const void* q_dev, size_t n, uint32_t what,
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   return check_dev(sc, q_dev, n, what, flags_dev, stream ? (hipStream_t)stream : sc->stream, false);
+}
+
+int gh_check_batch_noalloc(gh_scene* sc, const void* q_dev, size_t n, uint32_t what, uint8_t* flags_dev, void* stream) {
+  if (sc && !sc->parts.empty()) return fail(GH_ERR_INVALID, "device-pointer entry points take a single-device scene");
+  if (!sc || (n && (!q_dev || !flags_dev))) return fail(GH_ERR_INVALID, "null argument");
+  if (n && sc->D == 0) return fail(GH_ERR_DOF_MISMATCH, "scene has no batch columns");
+  if (n > kNoAllocMaxConfigs)
+    return fail(GH_ERR_TOO_LARGE, "gh_check_batch_noalloc takes at most " + std::to_string(kNoAllocMaxConfigs) +
+                " configurations per call (" + std::to_string(n) + " given): split the batch, or use gh_check_batch_dev");
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  Carve region;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    region.base = (char*)g_scratch_ptr[sc->device];  // set when the scene was created on this device
+  }
+  if (!region.base) return fail(GH_ERR_HIP, "no workspace address for this device");
+  region.bytes = kScratchBytes;
+  return check_dev(sc, q_dev, n, what, flags_dev, stream ? (hipStream_t)stream : sc->stream, false, &region);
 }
 
 int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags) {

@@ -20,7 +20,7 @@ SYMBOLS = [
     "gh_scene_create", "gh_scene_create_multi", "gh_scene_device_count", "gh_scene_destroy", "gh_scene_dof", "gh_scene_nodes", "gh_scene_precision",
     "gh_scene_device", "gh_check_batch", "gh_check_batch_dev", "gh_check_edges", "gh_check_edges_dev",
     "gh_fk_batch", "gh_fk_batch_dev", "gh_link_hits", "gh_link_mask_words", "gh_self_hits",
-    "gh_check_batch_counted", "gh_pipeline_last_stats", "gh_last_error", "gh_version",
+    "gh_check_batch_counted", "gh_check_batch_noalloc", "gh_pipeline_last_stats", "gh_last_error", "gh_version",
 ]
 
 
@@ -47,6 +47,7 @@ def lib():
             getattr(L, name).argtypes = [vp]
         L.gh_check_batch.argtypes = [vp, vp, sz, u32, vp]
         L.gh_check_batch_dev.argtypes = [vp, vp, sz, u32, vp, vp]
+        L.gh_check_batch_noalloc.argtypes = [vp, vp, sz, u32, vp, vp]
         L.gh_check_edges.argtypes = [vp, vp, vp, sz, u32, u8, vp, vp]
         L.gh_check_edges_dev.argtypes = [vp, vp, vp, sz, sz, u32, u8, vp, vp, vp]
         L.gh_fk_batch.argtypes = [vp, vp, sz, vp]

@@ -196,6 +196,20 @@ int gh_check_batch(gh_scene* scene, const void* q, size_t n, uint32_t what, uint
 int gh_check_batch_dev(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
                        uint8_t* flags_dev, void* hip_stream);
 
+/* gh_check_batch_dev for callers that must not allocate.  It has no counterpart in the reference; it is
+ * for code that cannot call hipMalloc while it runs: under HIP graph capture, in a tight serving loop, in a
+ * harness that forbids it.  Same arguments and the same bytes in flags_dev as gh_check_batch_dev, but the
+ * call makes no hipMalloc / hipFree (nor any other allocating call): the workspace of its kernels (hit
+ * words, the exact-stage entries of every sweep wavefront, counters, pose columns) is cut from one 64 MiB
+ * array that is part of the library's code object on every GPU, from the moment the code is loaded there
+ * until the process ends; its address on a device is looked up when a scene is created on that device.
+ * Limits: n <= 65536, and the workspace this scene needs for n configurations must fit the 64 MiB
+ * (GH_ERR_TOO_LARGE otherwise, with the number of configurations that do fit).  Every call on a GPU, from
+ * any scene, uses that GPU's one array: calls that overlap in time on one GPU race — serialise them (one
+ * stream, or events).  gh_pipeline_last_stats does not see these calls. */
+int gh_check_batch_noalloc(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
+                           uint8_t* flags_dev, void* hip_stream);
+
 /* Same, plus the first infeasible sample of each edge: the batched form of
  * rrt's stop-at-first-failure stepping (joint_path_planner.rs:168-188).
  * edge_off: [E+1] offsets into the n = edge_off[E] samples.
