@@ -109,8 +109,9 @@ template <class T> GD Pose<T> pose_mul(const Pose<T>& a, const Pose<T>& b) {
 
 // One step of k::Chain::update_transforms: world = parent * (origin * joint(q)).
 // (s, c) = sin, cos of position / 2 for a revolute joint (unused otherwise).
+// origin * joint(q): the node's transform relative to its parent
 template <class T>
-GD Pose<T> fk_step_sc(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position, T s, T c) {
+GD Pose<T> fk_local_sc(V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position, T s, T c) {
   Pose<T> local{ot, oq};
   if (joint_type == JT_ROT) {
     Q4<T> jq{axis.x * s, axis.y * s, axis.z * s, c};
@@ -118,7 +119,11 @@ GD Pose<T> fk_step_sc(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int
   } else if (joint_type == JT_LIN) {
     local.t = ot + qrot(oq, axis * position);
   }
-  return pose_mul(parent, local);
+  return local;
+}
+template <class T>
+GD Pose<T> fk_step_sc(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position, T s, T c) {
+  return pose_mul(parent, fk_local_sc(ot, oq, axis, joint_type, position, s, c));
 }
 template <class T>
 GD Pose<T> fk_step(const Pose<T>& parent, V3<T> ot, Q4<T> oq, V3<T> axis, int joint_type, T position) {

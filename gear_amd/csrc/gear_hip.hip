@@ -15,7 +15,7 @@
 
 #include "../../include/gear_hip.h"
 #include "gear_kernels.hpp"
-#include "gear_pipeline.hpp"
+#include "gear_small.hpp"
 #include "gear_scene.hpp"
 
 using namespace gear_hip;
@@ -112,6 +112,8 @@ struct Knobs {
   bool n2_hist = false;                 // GEAR_HIP_N2_HIST: histogram of GJK iterations (profiling)
   int n2_tile = 16;                     // GEAR_HIP_N2_TILE: sweep wavefronts per exact-stage workgroup (8, 16, 32)
   bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
+  size_t small_max = 8192;              // GEAR_HIP_SMALL_MAX: batches up to this size take k_small (0: never)
+  unsigned small_qcap = 2048;           // GEAR_HIP_SMALL_QCAP: item queue entries of a k_small workgroup (tests shrink it)
   static Knobs from_env() {
     Knobs k;
     auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 0) : dflt; };
@@ -128,6 +130,9 @@ struct Knobs {
     k.n2_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;
     k.n2_tile = (int)num("GEAR_HIP_N2_TILE", 16);
     k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
+    k.small_max = (size_t)std::max<long long>(0, num("GEAR_HIP_SMALL_MAX", 8192));
+    x = num("GEAR_HIP_SMALL_QCAP", 2048);
+    k.small_qcap = (unsigned)(x < 1 ? 1 : x > 8192 ? 8192 : x);
     return k;
   }
 };
@@ -185,6 +190,7 @@ struct gh_scene {
   bool has_mesh = false;
   Knobs knobs;
   CountersDev* counters = nullptr;
+  unsigned* small_done = nullptr;  // k_small's finished-workgroup ticket (behind `counters`; zero between calls)
   std::vector<gh_scene*> parts;  // gh_scene_create_multi: one scene per listed device; this object only routes
   size_t elem() const { return precision == 32 ? 4 : 8; }
 };
@@ -550,12 +556,56 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   return GH_OK;
 }
 
+// ---- small batches (gear_small.hpp): one launch, a configuration's work spread over many lanes ------
+constexpr uint32_t kForceSmall = 0x20u;
+constexpr size_t kSmallLdsMax = 64 * 1024;
+
+struct SmallEdges {  // gh_check_edges through k_small: the first-bad reduction rides in the same launch
+  const uint32_t* edge_off = nullptr;
+  size_t n_edges = 0;
+  uint8_t bad_mask = 0;
+  int32_t* first_bad = nullptr;
+  uint8_t* flags_near = nullptr;  // device copy of the flags when the caller's are host memory
+};
+constexpr size_t kSmallEdgesMax = 256;  // edges up to which the reduction rides in the k_small launch
+
+template <class T>
+SmallPlan small_plan_of(const gh_scene* sc, const SceneDev<T>& S) {
+  return plan_small<T>(S.n_nodes, S.n_shapes, S.n_spairs, S.n_limits, S.n_slots, sc->knobs.small_qcap);
+}
+
+template <class T>
+int small_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st,
+              const SmallEdges* ed) {
+  const SmallPlan sp = small_plan_of<T>(sc, S);
+  const int all_blk = (what & kNoGrid) ? S.all_blk : -1;
+  const size_t groups = (n + (size_t)sp.C - 1) / (size_t)sp.C;
+  hipLaunchKernelGGL((k_small<T>), dim3((unsigned)groups), dim3(kSmThreads), sp.lds, st, S, q, n, what, flags, sp.C, sp.qcap, all_blk,
+                     ed ? ed->edge_off : nullptr, ed ? (unsigned)ed->n_edges : 0u, ed ? (unsigned)ed->bad_mask : 0u,
+                     ed ? ed->first_bad : nullptr, ed ? ed->flags_near : nullptr, sc->small_done);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+// does this call take k_small?
+bool small_takes(const gh_scene* sc, size_t n, uint32_t what, bool counted) {
+  if (counted || !(what & 3u) || sc->L <= 0 || n == 0 || n >= (size_t(1) << 30)) return false;
+  if (what & (kForceFused | kForcePipe | 0x8000u)) return false;
+  if (!(what & kForceSmall) && n > sc->knobs.small_max) return false;
+  const size_t lds = sc->precision == 32 ? small_plan_of<float>(sc, sc->s32).lds : small_plan_of<double>(sc, sc->s64).lds;
+  return lds <= kSmallLdsMax;
+}
+
 int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted,
               Carve* fixed = nullptr) {
 #ifndef GEAR_HIP_ABLATE
   what &= kWhatPublic;  // undeclared bits never reach a kernel (the ablation build of tools/ keeps them)
 #endif
   if (!(sc->margin > 0)) what &= ~3u;  // distance >= 0 is never < a non-positive margin: only limits can fail
+  if (small_takes(sc, n, what, counted)) {
+    return sc->precision == 32 ? small_dev<float>(sc, sc->s32, (const float*)q, n, what, flags, st, nullptr)
+                               : small_dev<double>(sc, sc->s64, (const double*)q, n, what, flags, st, nullptr);
+  }
   bool pipe_ok = !counted && (what & 3u) && sc->L > 0 && !(what & kForceFused);
   if (pipe_ok && sc->knobs.small_fused && n < (size_t(1) << 14) && !(what & kForcePipe)) pipe_ok = false;
   if (pipe_ok) {
@@ -664,9 +714,10 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
             hipEventCreateWithFlags(&sc->ev_join[k], hipEventDisableTiming) != hipSuccess)
           rc = fail(GH_ERR_HIP, "hipStreamCreate failed");
       if (rc == GH_OK) {
-        if (hipMalloc((void**)&sc->counters, sizeof(CountersDev)) != hipSuccess ||
-            hipMemset(sc->counters, 0, sizeof(CountersDev)) != hipSuccess)
+        if (hipMalloc((void**)&sc->counters, sizeof(CountersDev) + 64) != hipSuccess ||
+            hipMemset(sc->counters, 0, sizeof(CountersDev) + 64) != hipSuccess)
           rc = fail(GH_ERR_HIP, "counter allocation failed");
+        else sc->small_done = reinterpret_cast<unsigned*>(sc->counters + 1);
       }
     }
   }
@@ -842,7 +893,18 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
 // flags of every sample + first flagged sample per edge; the caller holds the scene's Guard
 static int check_edges_locked(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges,
                               size_t n_samples, uint32_t what, uint8_t bad_mask, uint8_t* flags_dev,
-                              int32_t* first_bad_dev, hipStream_t st) {
+                              int32_t* first_bad_dev, hipStream_t st, bool exclusive = false, uint8_t* flags_near = nullptr) {
+#ifndef GEAR_HIP_ABLATE
+  what &= kWhatPublic;
+#endif
+  // exclusive: the caller keeps the scene's lock until the stream has drained (the host-buffer entry point),
+  // so the one ticket counter of the scene serves this call alone: one launch does everything
+  if (exclusive && n_edges > 0 && n_edges <= kSmallEdgesMax && sc->margin > 0 && small_takes(sc, n_samples, what, false)) {
+    SmallEdges ed;
+    ed.edge_off = edge_off_dev; ed.n_edges = n_edges; ed.bad_mask = bad_mask; ed.first_bad = first_bad_dev; ed.flags_near = flags_near;
+    return sc->precision == 32 ? small_dev<float>(sc, sc->s32, (const float*)q_dev, n_samples, what, flags_dev, st, &ed)
+                               : small_dev<double>(sc, sc->s64, (const double*)q_dev, n_samples, what, flags_dev, st, &ed);
+  }
   int rc = check_dev(sc, q_dev, n_samples, what, flags_dev, st, false);
   if (rc) return rc;
   if (n_edges) {
@@ -910,8 +972,9 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
       return rc;
     if (qb) std::memcpy(sc->hq.p, q, qb);
     std::memcpy(sc->hedges.p, edge_off, (n_edges + 1) * 4);
+    if ((rc = sc->flags.ensure(kZeroCopyMax))) return rc;
     if ((rc = check_edges_locked(sc, sc->hq.d, (const uint32_t*)sc->hedges.d, n_edges, n, what, bad_mask,
-                                 (uint8_t*)sc->hflags.d, (int32_t*)sc->hfirst.d, sc->stream)))
+                                 (uint8_t*)sc->hflags.d, (int32_t*)sc->hfirst.d, sc->stream, true, (uint8_t*)sc->flags.p)))
       return rc;
     GH_HIP(hipStreamSynchronize(sc->stream));
     if (n) std::memcpy(flags, sc->hflags.p, n);
@@ -924,7 +987,7 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
   if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
   GH_HIP(hipMemcpyAsync(sc->edges.p, edge_off, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
   if ((rc = check_edges_locked(sc, sc->q.p, (const uint32_t*)sc->edges.p, n_edges, n, what, bad_mask,
-                               (uint8_t*)sc->flags.p, (int32_t*)sc->first.p, sc->stream)))
+                               (uint8_t*)sc->flags.p, (int32_t*)sc->first.p, sc->stream, true)))
     return rc;
   if (n) GH_HIP(hipMemcpyAsync(flags, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
   GH_HIP(hipMemcpyAsync(first_bad, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));

@@ -32,7 +32,7 @@ constexpr int kWave = 64;
 // `what` bits a caller may pass (include/gear_hip.h): GH_CHECK_ENV | GH_CHECK_SELF | GH_CHECK_NO_LIMITS and
 // the GH_PATH_* / GH_COUNT_CANDIDATES evaluation hints.  Every extern "C" entry point masks `what` to
 // these, so a stray high bit can never change a result.
-constexpr uint32_t kWhatPublic = 0x3u | 0x10u | 0xf000u;
+constexpr uint32_t kWhatPublic = 0x3u | 0x10u | 0x20u | 0xf000u;
 constexpr uint32_t kWhatNoLimits = 0x10u;
 // Profiling ablations (skip a stage, force wave-uniform records, ...) give WRONG flags on purpose.  They
 // exist only in the -DGEAR_HIP_ABLATE build that tools/ablate_*.py load (gear_amd/build.py build_ablate);

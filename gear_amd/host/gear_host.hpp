@@ -816,16 +816,27 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
     st.samples += off.back();
     return eval(q, off);
   };
-  struct Iter { std::vector<N> q_new, line; int near_a, near_b; uint32_t m; Rng after; };
+  struct Iter { std::vector<N> q_rand, q_new, line; int near_a, near_b; uint32_t m; Rng after; };
+  // is vertex `stored` still what get_nearest_index(q) returns now that the tree has grown past `old_size`?
+  // (the scan keeps the first minimum, so a later vertex replaces it only when strictly nearer)
+  auto still_nearest = [dim](const Tree<N>& t, const N* q, int stored, size_t old_size) {
+    auto d2 = [&](const N* v) { N s = 0; for (size_t k = 0; k < dim; k++) s += (v[k] - q[k]) * (v[k] - q[k]); return s; };
+    const N bd = d2(t.at((size_t)stored));
+    for (size_t i = old_size; i < t.size(); i++)
+      if (d2(t.at(i)) < bd) return false;
+    return true;
+  };
   const size_t ahead = std::max<size_t>(lookahead, 1);
   size_t it = 0;
   while (it < num_max_try) {
     std::vector<Iter> iters;
     Rng r = rng;
     Tree<N>*ka = a, *kb = b;
+    const size_t size_a0 = a->size(), size_b0 = b->size();  // the trees the speculation looked at
     for (size_t k = 0; k < ahead && it + k < num_max_try; k++) {
       Iter x;
-      const std::vector<N> q_rand = random_sample(r);
+      x.q_rand = random_sample(r);
+      const std::vector<N>& q_rand = x.q_rand;
       x.near_a = ka->get_nearest_index(q_rand.data());
       x.q_new.resize(dim);
       step_towards(ka->at(x.near_a), q_rand.data(), dim, extend_length, x.q_new.data());
@@ -856,9 +867,20 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
           if (eval_counted(one, {0u, 1u})[0] >= 0) { bad[1] = (int32_t)k; break; }
         }
     }
-    bool applied = false;
+    // Iterations are consumed in order.  One that was applied has grown both trees; the next one's evaluation
+    // is still the sequential algorithm's as long as its two nearest-vertex lookups come out the same on the
+    // grown trees (then its extend sample and its connect line are the same too).  The first iteration for
+    // which they do not ends the batch: the random source goes back to its state before that iteration.
+    size_t last = 0;
+    bool grown = false;
+    Tree<N>* const a0 = a;  // the tree whose size was size_a0
     for (size_t k = 0; k < iters.size(); k++) {
       Iter& x = iters[k];
+      if (grown) {
+        const size_t old_a = a == a0 ? size_a0 : size_b0, old_b = b == a0 ? size_a0 : size_b0;
+        if (!still_nearest(*a, x.q_rand.data(), x.near_a, old_a) || !still_nearest(*b, x.q_new.data(), x.near_b, old_b)) break;
+      }
+      last = k;
       it++;
       st.iterations++;
       st.consumed++;
@@ -880,11 +902,9 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
         return a_all;
       }
       std::swap(a, b);
-      rng = x.after;
-      applied = true;
-      break;
+      grown = true;
     }
-    if (!applied) rng = iters.back().after;
+    rng = iters[last].after;
   }
   throw Error(Error::PathPlanFail, "failed");
 }
@@ -971,7 +991,7 @@ template <class N> class JointPathPlanner {
   // not in the reference: where and how the batched engine runs
   int device = 0;
   bool speculate = true;            // hand whole lines, and several iterations / trials, to the GPU per call
-  size_t rrt_lookahead = 4;         // RRT iterations evaluated per GPU call when speculating (4: 60 ms, 8: 64 ms, 2: 69 ms, 16: 78 ms per plan in the 96-obstacle field)
+  size_t rrt_lookahead = 12;        // RRT iterations drawn ahead per GPU call when speculating (plan in the 96-obstacle field: 4: 29 ms, 8: 19 ms, 12: 17.3 ms, 16: 17.3 ms, 32: 21 ms; tools/plan_time.py)
   size_t smoothing_lookahead = 16;  // smoothing trials evaluated per GPU call when speculating
   Rng rng{0};
   rrt::Stats stats;

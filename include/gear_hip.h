@@ -75,13 +75,15 @@ enum {
  * Every entry point ignores bits of `what` that are not declared in this header. */
 enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2, GH_CHECK_NO_LIMITS = 0x10 };
 /* optional `what` bits that only choose HOW the batch is evaluated; the result
- * bytes are identical either way (tests/test_gpu_pipeline.py).  Without them
- * a scene with a broadphase grid (>= 32 obstacles) takes the multi-kernel
- * pipeline at every batch size; other scenes take it from 16384 configurations
- * and the single fused kernel below.  No counterpart in the reference. */
-enum { GH_PATH_FUSED = 0x1000, GH_PATH_PIPELINE = 0x2000,
-       GH_PATH_NO_GRID = 0x4000, /* pipeline: sweep every obstacle instead of the broadphase grid's cell lists */
-       GH_COUNT_CANDIDATES = 0x8000 /* count the broadphase candidates (gh_pipeline_last_stats) */ };
+ * bytes are identical either way (tests/test_gpu_pipeline.py, tests/test_gpu_small.py).
+ * Without them a call of up to 8192 configurations takes the single-launch
+ * small-batch kernel (a configuration's work spread over many lanes: the RRT
+ * lines of joint_path_planner.rs:168-188), larger ones the multi-kernel
+ * pipeline; the fused kernel serves scenes whose tables do not fit either.
+ * No counterpart in the reference. */
+enum { GH_PATH_SMALL = 0x20, GH_PATH_FUSED = 0x1000, GH_PATH_PIPELINE = 0x2000,
+       GH_PATH_NO_GRID = 0x4000, /* sweep every obstacle instead of the broadphase grid's cell lists */
+       GH_COUNT_CANDIDATES = 0x8000 /* count the broadphase candidates (gh_pipeline_last_stats); implies the pipeline */ };
 
 /* ---- descriptors ------------------------------------------------------- */
 
