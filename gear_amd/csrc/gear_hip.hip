@@ -113,7 +113,7 @@ struct Knobs {
   int n2_tile = 16;                     // GEAR_HIP_N2_TILE: sweep wavefronts per exact-stage workgroup (8, 16, 32)
   bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
   size_t small_max = 8192;              // GEAR_HIP_SMALL_MAX: batches up to this size take k_small (0: never)
-  unsigned small_qcap = 2048;           // GEAR_HIP_SMALL_QCAP: item queue entries of a k_small workgroup (tests shrink it)
+  unsigned small_qcap = 1024;           // GEAR_HIP_SMALL_QCAP: item queue entries of a k_small workgroup (tests shrink it)
   static Knobs from_env() {
     Knobs k;
     auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? strtoll(e, nullptr, 0) : dflt; };
@@ -131,7 +131,7 @@ struct Knobs {
     k.n2_tile = (int)num("GEAR_HIP_N2_TILE", 16);
     k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
     k.small_max = (size_t)std::max<long long>(0, num("GEAR_HIP_SMALL_MAX", 8192));
-    x = num("GEAR_HIP_SMALL_QCAP", 2048);
+    x = num("GEAR_HIP_SMALL_QCAP", 1024);
     k.small_qcap = (unsigned)(x < 1 ? 1 : x > 8192 ? 8192 : x);
     return k;
   }
@@ -570,17 +570,17 @@ struct SmallEdges {  // gh_check_edges through k_small: the first-bad reduction 
 constexpr size_t kSmallEdgesMax = 256;  // edges up to which the reduction rides in the k_small launch
 
 template <class T>
-SmallPlan small_plan_of(const gh_scene* sc, const SceneDev<T>& S) {
-  return plan_small<T>(S.n_nodes, S.n_shapes, S.n_spairs, S.n_limits, S.n_slots, sc->knobs.small_qcap);
+SmallPlan small_plan_of(const gh_scene* sc, const SceneDev<T>& S, size_t n) {
+  return plan_small<T>(S.n_nodes, S.n_shapes, S.n_spairs, S.n_limits, S.n_slots, S.n_obs, sc->knobs.small_qcap, n);
 }
 
 template <class T>
 int small_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st,
               const SmallEdges* ed) {
-  const SmallPlan sp = small_plan_of<T>(sc, S);
+  const SmallPlan sp = small_plan_of<T>(sc, S, n);
   const int all_blk = (what & kNoGrid) ? S.all_blk : -1;
   const size_t groups = (n + (size_t)sp.C - 1) / (size_t)sp.C;
-  hipLaunchKernelGGL((k_small<T>), dim3((unsigned)groups), dim3(kSmThreads), sp.lds, st, S, q, n, what, flags, sp.C, sp.qcap, all_blk,
+  hipLaunchKernelGGL((k_small<T>), dim3((unsigned)groups), dim3(kSmThreads), sp.lds, st, S, q, n, what, flags, sp.C, sp.qcap, all_blk, sp.cull_lds ? 1 : 0,
                      ed ? ed->edge_off : nullptr, ed ? (unsigned)ed->n_edges : 0u, ed ? (unsigned)ed->bad_mask : 0u,
                      ed ? ed->first_bad : nullptr, ed ? ed->flags_near : nullptr, sc->small_done);
   GH_HIP(hipGetLastError());
@@ -589,10 +589,10 @@ int small_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t
 
 // does this call take k_small?
 bool small_takes(const gh_scene* sc, size_t n, uint32_t what, bool counted) {
-  if (counted || !(what & 3u) || sc->L <= 0 || n == 0 || n >= (size_t(1) << 30)) return false;
+  if (counted || !(what & 3u) || sc->L <= 0 || n == 0 || n >= (size_t(1) << 30) || sc->N > 4000) return false;  // (the walk packs slot indices in 12 bits)
   if (what & (kForceFused | kForcePipe | 0x8000u)) return false;
   if (!(what & kForceSmall) && n > sc->knobs.small_max) return false;
-  const size_t lds = sc->precision == 32 ? small_plan_of<float>(sc, sc->s32).lds : small_plan_of<double>(sc, sc->s64).lds;
+  const size_t lds = sc->precision == 32 ? small_plan_of<float>(sc, sc->s32, n).lds : small_plan_of<double>(sc, sc->s64, n).lds;
   return lds <= kSmallLdsMax;
 }
 
