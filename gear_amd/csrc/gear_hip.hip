@@ -168,6 +168,23 @@ struct Carve {
 };
 }  // namespace
 
+// ---- the pipeline's workspace: ONE pool per device, shared by every scene on it ---------------------
+// A planner holds a scene per (joint set, obstacle set); a workspace set is ~230 MB for a 1M-configuration
+// chunk of the metric scene (f32), four times that for mesh scenes, and up to four sets are in flight in one
+// call.  Scenes therefore own only their tables and staging buffers; the sets live here, grow to the
+// largest call seen on the device, and are freed when the device's last scene is destroyed.  Calls on
+// different scenes and streams may overlap in time, so a set carries the event of its last use: whoever
+// takes it next makes its stream wait for that event first (the enqueue itself runs under the pool's lock).
+struct PipeBufs { DevBuf hit, xcnt, xkey, xpose_a, xpose_b, fq, pc; hipEvent_t last_use = nullptr; bool used = false; };
+struct PipePool {
+  std::mutex mu;
+  PipeBufs sets[kMaxSets];
+  int scenes = 0;
+};
+namespace {
+PipePool g_pool[kMaxDevices];
+}
+
 struct gh_scene {
   int precision = 32, device = 0;
   int D = 0, N = 0, L = 0, O = 0, P = 0, n_slots = 0;
@@ -180,9 +197,9 @@ struct gh_scene {
   std::mutex mu;
   DevBuf q, flags, out, edges, store, first;
   PinBuf hq, hflags, hedges, hfirst;  // small host-buffer calls run on these in place
-  // pipeline workspace (gear_pipeline.hpp): several sets, so that consecutive chunks of one call can be
-  // in flight together (set 0 on the caller's stream, set k on aux[k])
-  struct PipeBufs { DevBuf hit, xcnt, xkey, xpose_a, xpose_b, fq, pc; } pw[kMaxSets];
+  // the pipeline's workspace sets are the device's (PipePool); consecutive chunks of one call take different
+  // sets so that they can be in flight together (set 0 on the caller's stream, set k on aux[k])
+  bool pooled = false;  // this scene is counted in its device's PipePool
   hipStream_t aux[kMaxSets] = {};  // aux[0] unused: set 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSets] = {};
   int last_sets = 0;  // workspace sets the last pipeline call used
@@ -466,9 +483,15 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
                   " (about " + std::to_string(fixed->bytes / per_wave * kWave) + " configurations of this scene per call)");
     }
   }
+  PipePool& pool = g_pool[sc->device];
+  std::unique_lock<std::mutex> pool_lock(pool.mu, std::defer_lock);
+  if (!fixed) pool_lock.lock();  // held until every launch of this call is enqueued
   for (int k = 0; k < n_sets && !fixed; k++) {
     PipeWs<T>& W = Ws[k];
-    gh_scene::PipeBufs& b = sc->pw[k];
+    PipeBufs& b = pool.sets[k];
+    if (!b.last_use) GH_HIP(hipEventCreateWithFlags(&b.last_use, hipEventDisableTiming));
+    // whatever used this set last (another scene, another stream) finishes before this call touches it
+    if (b.used) GH_HIP(hipStreamWaitEvent(k ? sc->aux[k] : st, b.last_use, 0));
     W = PipeWs<T>{};
     W.capw = capw;
     if ((rc = b.hit.ensure(chunk * 4)) || (rc = b.xcnt.ensure(waves * 4)) || (rc = b.xkey.ensure(waves * capw * 8)) ||
@@ -546,6 +569,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     }
     launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
     GH_HIP(hipGetLastError());
+  }
+  for (int k = 0; k < n_sets && !fixed; k++) {
+    GH_HIP(hipEventRecord(pool.sets[k].last_use, k ? sc->aux[k] : st));
+    pool.sets[k].used = true;
   }
   if (two) {
     for (int k = 1; k < n_sets; k++) {
@@ -727,6 +754,11 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
     g_last_error = keep;
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    g_pool[device].scenes++;
+    sc->pooled = true;
+  }
   *out = sc;
   return GH_OK;
 }
@@ -778,8 +810,18 @@ void gh_scene_destroy(gh_scene* sc) {
       if (sc->ev_join[k]) (void)hipEventDestroy(sc->ev_join[k]);
     }
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
-    for (auto& b : sc->pw) {
-      b.hit.release(); b.xcnt.release(); b.xkey.release(); b.xpose_a.release(); b.xpose_b.release(); b.fq.release(); b.pc.release();
+    if (sc->pooled) {  // the device's last scene takes the workspace pool with it
+      PipePool& pool = g_pool[sc->device];
+      std::lock_guard<std::mutex> lk(pool.mu);
+      if (--pool.scenes == 0) {
+        (void)hipDeviceSynchronize();
+        for (auto& b : pool.sets) {
+          b.hit.release(); b.xcnt.release(); b.xkey.release(); b.xpose_a.release(); b.xpose_b.release(); b.fq.release(); b.pc.release();
+          if (b.last_use) (void)hipEventDestroy(b.last_use);
+          b.last_use = nullptr;
+          b.used = false;
+        }
+      }
     }
   }
   delete sc;
@@ -875,10 +917,12 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   out[0] = out[1] = out[2] = out[3] = 0;
-  if (!sc->pw[0].pc.p) return GH_OK;
+  PipePool& pool = g_pool[sc->device];
+  std::lock_guard<std::mutex> lk(pool.mu);
+  if (!pool.sets[0].pc.p) return GH_OK;
   GH_HIP(hipDeviceSynchronize());
   for (int k = 0; k < sc->last_sets; k++) {  // the last chunk of each workspace set the last call used
-    gh_scene::PipeBufs& b = sc->pw[k];
+    PipeBufs& b = pool.sets[k];
     if (!b.pc.p) continue;
     PipeCounters h;
     GH_HIP(hipMemcpy(&h, b.pc.p, sizeof(h), hipMemcpyDeviceToHost));

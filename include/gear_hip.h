@@ -250,7 +250,8 @@ int gh_check_batch_counted(gh_scene* scene, const void* q_dev, size_t n, uint32_
                            uint8_t* flags_dev, gh_counters* out);
 
 /* Diagnostic, no counterpart in the reference: counters of the last call on this scene that carried
- * GH_COUNT_CANDIDATES in `what`, summed over the last chunk of each workspace set it used (synchronises
+ * GH_COUNT_CANDIDATES in `what` (the counters live in the device's shared workspace: read them before
+ * another scene of the same device runs a large batch), summed over the last chunk of each workspace set it used (synchronises
  * the device).  out[0] broadphase candidates tested, out[1] items handed to the exact stage, out[2]
  * sweep wavefronts whose exact region ran full (their configurations were re-checked by the fused
  * kernel), out[3] exact entries a sweep wavefront may write. */

@@ -151,3 +151,36 @@ def test_scene_cache_follows_compound_contents(tmp_path, sample_robot):
         assert pl.is_feasible(u, q, far) is True, k
         assert pl.colliding_link_names(far) == []
         del far
+
+
+def test_scenes_share_the_device_workspace():
+    """The pipeline's workspace belongs to the device, not to a scene: calls on different scenes — other
+    robots, other precisions, other sizes, from different host threads — take the same sets one after the
+    other and each still gets its own bytes."""
+    cases = []
+    for w, prec, n in ((W.metric_workload(), 32, 90000), (W.pr2_workload(64), 64, 30000), (W.ur10_workload(96), 32, 50000)):
+        hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+        q = w.configs(n, seed=47, dtype=hip.dtype, overshoot=0.01)
+        cases.append((hip, q, hip.check_batch(q, BOTH | D.GH_PATH_FUSED)))
+    errors = []
+
+    def loop(k):
+        hip, q, want = cases[k]
+        for r in range(6):
+            m = len(q) - 997 * r                                  # sizes change, so the sets are regrown and reused
+            if not (hip.check_batch(q[:m], BOTH | D.GH_PATH_PIPELINE) == want[:m]).all():
+                errors.append((k, r))
+
+    ts = [threading.Thread(target=loop, args=(k,)) for k in range(len(cases))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    # destroying every scene of the device frees the pool; the next scene starts a new one
+    for hip, _, _ in cases:
+        hip.close()
+    w = W.metric_workload()
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    q = w.configs(20000, seed=48, overshoot=0.01)
+    assert (hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE) == hip.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
