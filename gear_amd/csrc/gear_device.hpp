@@ -422,6 +422,7 @@ template <class T> GD int sat_box_box(V3<T> a, V3<T> b, const Rel<T>& rel, T m) 
 template <class T, class VP, class PP>
 GD bool inside_with_clearance(const ShapeRef<T>& P, const ShapeRef<T>& X, const Rel<T>& rel, bool p_is_a,
                               VP verts, PP planes, T m) {
+  if (P.fc == 0) return false;           // a lone triangle of a general mesh encloses nothing
   if (X.br > T(2) * P.br) return false;  // enclosing-ball argument: X inside P needs br(X) <= 2 br(P)
   T xr = X.kind == SK_BALL ? X.half.x : T(0);
   // cheap necessary condition first, for the kinds whose frame origin is a point of their core (box,

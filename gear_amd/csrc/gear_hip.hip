@@ -188,6 +188,7 @@ PipePool g_pool[kMaxDevices];
 struct gh_scene {
   int precision = 32, device = 0;
   int D = 0, N = 0, L = 0, O = 0, P = 0, n_slots = 0;
+  int O_user = 0;  // obstacle shapes as the caller counts them (O counts a general mesh's triangles one by one)
   int max_shape_node = -1;  // last node that owns a robot shape
   double margin = 0;
   SceneDev<float> s32{};
@@ -266,6 +267,9 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
     std::copy(H.planes.begin(), H.planes.end(), m4.begin() + (size_t)4 * S.n_verts);
     if ((rc = upload(sc, m4, &S.mesh4))) return rc;
   }
+  if ((rc = upload(sc, H.obs_owner, &S.obs_owner))) return rc;
+  S.n_obs_user = H.n_obs_user;
+  sc->O_user = H.n_obs_user;
   if ((rc = upload(sc, H.grids, &S.grids))) return rc;
   if ((rc = upload(sc, H.shape_grid, &S.shape_grid))) return rc;
   if ((rc = upload(sc, H.cell_blk, &S.cell_blk))) return rc;
@@ -784,7 +788,7 @@ int gh_scene_create_multi(const gh_robot_desc* robot, const gh_obstacle_desc* ob
   }
   const gh_scene* p0 = grp->parts[0];
   grp->precision = p0->precision; grp->device = p0->device; grp->margin = p0->margin;
-  grp->D = p0->D; grp->N = p0->N; grp->L = p0->L; grp->O = p0->O; grp->P = p0->P;
+  grp->D = p0->D; grp->N = p0->N; grp->L = p0->L; grp->O = p0->O; grp->O_user = p0->O_user; grp->P = p0->P;
   *out = grp;
   return GH_OK;
 }
@@ -1079,7 +1083,7 @@ int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t*
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
   int W = (sc->N + 63) / 64, rc;
-  size_t qb = n * sc->D * sc->elem(), mb = n * sc->O * W * 8;
+  size_t qb = n * sc->D * sc->elem(), mb = n * sc->O_user * W * 8;
   if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->out.ensure(mb))) return rc;
   if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
   if (!(sc->margin > 0)) {
@@ -1087,7 +1091,7 @@ int gh_link_hits(gh_scene* sc, const void* q, size_t n, uint32_t what, uint64_t*
   } else {
     StorePlan plan = plan_store(sc, true);
     rc = for_chunks(sc, n, plan, [&](size_t off, size_t cnt, void* gs, size_t gstride) {
-      unsigned long long* m = (unsigned long long*)sc->out.p + off * sc->O * W;
+      unsigned long long* m = (unsigned long long*)sc->out.p + off * sc->O_user * W;
       if (sc->precision == 32)
         hipLaunchKernelGGL((k_link_hits<float>), dim3(grid_for(cnt)), dim3(kWave), plan.lds_bytes, sc->stream, sc->s32,
                            (const float*)sc->q.p + off * sc->D, cnt, what & kWhatPublic, m, W, (float*)gs, gstride);

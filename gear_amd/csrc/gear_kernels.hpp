@@ -577,11 +577,15 @@ k_link_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uns
   const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow);  // GH_CHECK_NO_LIMITS: geometry only
   walk_store_shapes(S, V, qrow, st);
   LaneCounters lc{0, 0, 0, 0};
+  const GEAR_CAS int32_t* owner = to_cas(S.obs_owner);
+  unsigned long long m0 = 0, m1 = 0;
   for (int o = 0; o < S.n_obs; o++) {
     const GEAR_CAS ShapeDev<T>* ob = V.oshapes + o;
     const ShapeRef<T> B = shape_ref<T>(ob);
     const Pose<T> wb = shape_pose<T>(ob);
-    unsigned long long m0 = 0, m1 = 0;
+    // the triangles of a general mesh are consecutive device obstacles with one owner: their bits are OR-ed
+    // (the reference tests the link against the whole mesh: a minimum over its triangles)
+    if (o == 0 || owner[o] != owner[o - 1]) m0 = m1 = 0;
     for (int s = 0; s < S.n_shapes; s++) {
       const GEAR_CAS ShapeDev<T>* sh = V.rshapes + s;
       const int node = sh->node;
@@ -597,8 +601,8 @@ k_link_hits(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uns
         }
       }
     }
-    if (live) {
-      unsigned long long* out = masks + (i * (size_t)S.n_obs + o) * W;
+    if (live && (o == S.n_obs - 1 || owner[o + 1] != owner[o])) {
+      unsigned long long* out = masks + (i * (size_t)S.n_obs_user + (size_t)owner[o]) * W;
       out[0] = ok ? m0 : 0ull;
       if (W > 1) out[1] = ok ? m1 : 0ull;
     }

@@ -27,6 +27,8 @@ struct HostTables {
   std::vector<NodeDev<T>> nodes;
   std::vector<LimitDev<T>> limits;
   std::vector<ShapeDev<T>> rshapes, oshapes;
+  std::vector<int32_t> obs_owner;  // [oshapes] the caller's obstacle index of every device obstacle shape (a mesh may be many)
+  int n_obs_user = 0;
   std::vector<T> ocull, ocullq;
   std::vector<PairDev> pairs;
   std::vector<int32_t> spairs;  // flattened self shape pairs: [n][4] = s1, s2, node-pair index, LDS slot of the earlier shape
@@ -130,9 +132,17 @@ inline bool convex_planes(const std::vector<double>& v, const std::vector<int>& 
   return true;
 }
 
+// One descriptor -> one device shape, or — a mesh that is not a closed convex polytope — one device shape PER
+// TRIANGLE.  The reference turns any mesh file into an ncollide TriMesh, a triangle soup whose distance to
+// another shape is the minimum over its triangles (src/collision/urdf.rs:54-71, mesh.rs:39-69), and the path
+// only asks "is that minimum below the margin", which is an OR over the triangles.  So a general mesh joins the
+// scene as its triangles: each is a convex piece with three vertices and no face planes (nothing can be
+// "inside" it), each has its own bounding sphere, and the broadphase grid does for them what a BVH would.
+// A closed convex mesh stays ONE shape (hull + the hollow-surface rule): the same answers from one GJK query
+// instead of one per triangle.  `piece_of` is the caller's index of the descriptor, repeated per piece.
 template <class T>
 inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, int n_meshes, int node,
-                          HostTables<T>& H, ShapeDev<T>& out, BuildError& err) {
+                          HostTables<T>& H, std::vector<ShapeDev<T>>& out, BuildError& err) {
   ShapeDev<T> s{};
   for (int k = 0; k < 3; k++) s.lt[k] = T(d.t[k]);
   for (int k = 0; k < 4; k++) s.lq[k] = T(d.q[k]);
@@ -140,6 +150,47 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
   s.v_begin = s.v_count = s.f_begin = s.f_count = 0;
   s.prism_n = 0;
   auto bad = [&](const char* m) { err = {GH_ERR_INVALID, m}; return false; };
+  // a convex piece given by its vertices (and, for a closed polytope, its face planes): re-centred on the centre
+  // of its bounding box, the shift folded into the shape's pose (t += R(q) c), so that for every shape kind the
+  // bounding sphere sits at the pose translation
+  auto emit_polytope = [&](const std::vector<double>& v, const std::vector<double>& planes, int prism_n) {
+    ShapeDev<T> m = s;
+    m.kind = SK_MESH;
+    m.prism_n = prism_n;
+    m.v_begin = (int)(H.verts.size() / 3);
+    m.v_count = (int)(v.size() / 3);
+    m.f_begin = (int)(H.planes.size() / 4);
+    m.f_count = (int)(planes.size() / 4);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < v.size() / 3; i++)
+      for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], v[3 * i + k]); hi[k] = std::max(hi[k], v[3 * i + k]); }
+    double c[3] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2}, r2 = 0;
+    for (size_t i = 0; i < v.size() / 3; i++) {
+      double dd = 0;
+      for (int k = 0; k < 3; k++) dd += (v[3 * i + k] - c[k]) * (v[3 * i + k] - c[k]);
+      r2 = std::max(r2, dd);
+    }
+    {
+      double q[4] = {d.q[0], d.q[1], d.q[2], d.q[3]};
+      double tx = 2 * (q[1] * c[2] - q[2] * c[1]), ty = 2 * (q[2] * c[0] - q[0] * c[2]), tz = 2 * (q[0] * c[1] - q[1] * c[0]);
+      double rc[3] = {c[0] + q[3] * tx + (q[1] * tz - q[2] * ty), c[1] + q[3] * ty + (q[2] * tx - q[0] * tz),
+                      c[2] + q[3] * tz + (q[0] * ty - q[1] * tx)};
+      for (int k = 0; k < 3; k++) m.lt[k] = T(d.t[k] + rc[k]);
+    }
+    for (int k = 0; k < 3; k++) m.bc[k] = T(0);
+    // local bounding box (centred after the shift), padded a little: stage 1 uses it as a prefilter
+    for (int k = 0; k < 3; k++) m.half[k] = T((hi[k] - lo[k]) * 0.5 * (1.0 + 1e-6) + 1e-9);
+    m.br = T(std::sqrt(r2) * (1.0 + 1e-6) + 1e-12);
+    for (size_t i = 0; i < v.size(); i++) H.verts.push_back(T(v[i] - c[i % 3]));
+    for (size_t pl = 0; pl < planes.size() / 4; pl++) {
+      double off = planes[4 * pl + 3] - (planes[4 * pl] * c[0] + planes[4 * pl + 1] * c[1] + planes[4 * pl + 2] * c[2]);
+      H.planes.push_back(T(planes[4 * pl]));
+      H.planes.push_back(T(planes[4 * pl + 1]));
+      H.planes.push_back(T(planes[4 * pl + 2]));
+      H.planes.push_back(T(off));
+    }
+    out.push_back(m);
+  };
   switch (d.kind) {
     case GH_SHAPE_BOX: {
       s.kind = SK_BOX;
@@ -150,6 +201,7 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
         r2 += (double)s.half[k] * (double)s.half[k];
       }
       s.br = T(std::sqrt(r2) * (1.0 + 1e-6));
+      out.push_back(s);
       break;
     }
     case GH_SHAPE_BALL:
@@ -157,6 +209,7 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
       s.kind = SK_BALL;
       s.half[0] = T(d.params[0]);
       s.br = s.half[0];
+      out.push_back(s);
       break;
     case GH_SHAPE_CYLINDER:
     case GH_SHAPE_MESH: {
@@ -171,52 +224,28 @@ inline bool flatten_shape(const gh_shape_desc& d, const gh_mesh_desc* meshes, in
         if (m.n_vertices <= 0 || m.n_triangles <= 0 || !m.vertices || !m.triangles) return bad("empty mesh");
         for (int i = 0; i < 3 * m.n_vertices; i++) v.push_back((double)T(m.vertices[i]));
         tris.assign(m.triangles, m.triangles + 3 * m.n_triangles);
+        for (int t : tris)
+          if (t < 0 || t >= m.n_vertices) return bad("mesh triangle index out of range");
       }
       std::vector<double> planes;
       std::string why;
-      if (!convex_planes(v, tris, planes, why)) { err = {GH_ERR_NONCONVEX, why}; return false; }
-      s.kind = SK_MESH;
-      s.prism_n = d.kind == GH_SHAPE_CYLINDER ? 30 : 0;
-      s.v_begin = (int)(H.verts.size() / 3);
-      s.v_count = (int)(v.size() / 3);
-      s.f_begin = (int)(H.planes.size() / 4);
-      s.f_count = (int)(planes.size() / 4);
-      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-      for (size_t i = 0; i < v.size() / 3; i++)
-        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], v[3 * i + k]); hi[k] = std::max(hi[k], v[3 * i + k]); }
-      double c[3] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2}, r2 = 0;
-      for (size_t i = 0; i < v.size() / 3; i++) {
-        double dd = 0;
-        for (int k = 0; k < 3; k++) dd += (v[3 * i + k] - c[k]) * (v[3 * i + k] - c[k]);
-        r2 = std::max(r2, dd);
+      if (convex_planes(v, tris, planes, why) && v.size() / 3 <= 64) {
+        emit_polytope(v, planes, d.kind == GH_SHAPE_CYLINDER ? 30 : 0);
+        break;
       }
-      // re-centre the mesh on its bounding-sphere centre and fold the shift into the shape's pose
-      // (t += R(q) c), so that for every shape kind the bounding sphere sits at the pose translation
-      {
-        double q[4] = {d.q[0], d.q[1], d.q[2], d.q[3]};
-        double tx = 2 * (q[1] * c[2] - q[2] * c[1]), ty = 2 * (q[2] * c[0] - q[0] * c[2]), tz = 2 * (q[0] * c[1] - q[1] * c[0]);
-        double rc[3] = {c[0] + q[3] * tx + (q[1] * tz - q[2] * ty), c[1] + q[3] * ty + (q[2] * tx - q[0] * tz),
-                        c[2] + q[3] * tz + (q[0] * ty - q[1] * tx)};
-        for (int k = 0; k < 3; k++) s.lt[k] = T(d.t[k] + rc[k]);
-      }
-      for (int k = 0; k < 3; k++) s.bc[k] = T(0);
-      // local bounding box (centred after the shift), padded a little: stage 1 uses it as a prefilter
-      for (int k = 0; k < 3; k++) s.half[k] = T((hi[k] - lo[k]) * 0.5 * (1.0 + 1e-6) + 1e-9);
-      s.br = T(std::sqrt(r2) * (1.0 + 1e-6));
-      for (size_t i = 0; i < v.size(); i++) H.verts.push_back(T(v[i] - c[i % 3]));
-      for (size_t pl = 0; pl < planes.size() / 4; pl++) {
-        double off = planes[4 * pl + 3] - (planes[4 * pl] * c[0] + planes[4 * pl + 1] * c[1] + planes[4 * pl + 2] * c[2]);
-        H.planes.push_back(T(planes[4 * pl]));
-        H.planes.push_back(T(planes[4 * pl + 1]));
-        H.planes.push_back(T(planes[4 * pl + 2]));
-        H.planes.push_back(T(off));
+      if (d.kind == GH_SHAPE_CYLINDER) { err = {GH_ERR_INVALID, "internal: the cylinder's prism is not convex: " + why}; return false; }
+      // a triangle soup: one piece per triangle
+      for (size_t t = 0; t < tris.size() / 3; t++) {
+        std::vector<double> tv;
+        for (int e = 0; e < 3; e++)
+          for (int k = 0; k < 3; k++) tv.push_back(v[3 * (size_t)tris[3 * t + e] + k]);
+        emit_polytope(tv, {}, 0);
       }
       break;
     }
     default:
       return bad("unknown shape kind");
   }
-  out = s;
   return true;
 }
 
@@ -425,18 +454,35 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
   for (int k = 0; k < N; k++) {
     H.nodes[k].shape_begin = (int)H.rshapes.size();
     for (int s : by_node[k]) {
-      ShapeDev<T> sd;
-      if (!detail::flatten_shape<T>(r.shapes[s], r.meshes, r.n_meshes, k, H, sd, err)) return false;
-      br_max = std::max(br_max, sd.br);
-      H.rshapes.push_back(sd);
+      std::vector<ShapeDev<T>> pieces;
+      if (!detail::flatten_shape<T>(r.shapes[s], r.meshes, r.n_meshes, k, H, pieces, err)) return false;
+      for (const ShapeDev<T>& sd : pieces) {
+        br_max = std::max(br_max, sd.br);
+        H.rshapes.push_back(sd);
+      }
     }
     H.nodes[k].shape_end = (int)H.rshapes.size();
   }
+  if (H.rshapes.size() > 1023) {
+    err = {GH_ERR_TOO_LARGE, "at most 1023 robot collision shapes, counting every triangle of a link mesh that is not a closed convex polytope (" +
+                                 std::to_string(H.rshapes.size()) + " here)"};
+    return false;
+  }
   std::vector<std::array<double, 5>> cull_rec;
   // obstacles: world poses; cull record = world bounding sphere, radius pre-inflated by the margin
+  std::vector<ShapeDev<T>> opieces;
   for (int s = 0; s < o.n_shapes; s++) {
-    ShapeDev<T> sd;
-    if (!detail::flatten_shape<T>(o.shapes[s], o.meshes, o.n_meshes, -1, H, sd, err)) return false;
+    const size_t before = opieces.size();
+    if (!detail::flatten_shape<T>(o.shapes[s], o.meshes, o.n_meshes, -1, H, opieces, err)) return false;
+    for (size_t k = before; k < opieces.size(); k++) H.obs_owner.push_back(s);
+  }
+  H.n_obs_user = o.n_shapes;
+  if (opieces.size() > 32767) {
+    err = {GH_ERR_TOO_LARGE, "at most 32767 obstacle shapes, counting every triangle of a mesh that is not a closed convex polytope (" +
+                                 std::to_string(opieces.size()) + " here)"};
+    return false;
+  }
+  for (const ShapeDev<T>& sd : opieces) {
     H.oshapes.push_back(sd);
     // centre = t + R(q) * bc, in double
     double q[4] = {(double)sd.lq[0], (double)sd.lq[1], (double)sd.lq[2], (double)sd.lq[3]};

@@ -125,6 +125,10 @@ struct SceneDev {
   // with one 16-byte access
   const T* mesh4;               // [(n_verts + n_planes)][4]
   int32_t n_verts, n_planes;
+  // obstacle shapes as the CALLER counts them: a mesh that is not a closed convex polytope is one device shape
+  // per triangle (gear_scene.hpp flatten_shape); obs_owner[o] is the caller's index of device obstacle o
+  const int32_t* obs_owner;     // [n_obs]
+  int32_t n_obs_user, pad3;
 };
 
 }  // namespace gear_hip

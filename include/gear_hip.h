@@ -45,7 +45,7 @@ typedef enum gh_status {
   GH_ERR_DOF_MISMATCH = -2, /* cf. gear::Error::DofMismatch (errors.rs:48)    */
   GH_ERR_HIP = -3,          /* a HIP runtime call failed                      */
   GH_ERR_TOO_LARGE = -4,    /* scene exceeds a documented capacity            */
-  GH_ERR_NONCONVEX = -5,    /* mesh is not a closed convex polytope           */
+  GH_ERR_NONCONVEX = -5,    /* (not returned any more: see GH_SHAPE_MESH)     */
   GH_ERR_NO_DEVICE = -6     /* HIP device missing: the product never falls
                                back to a CPU path                             */
 } gh_status;
@@ -57,7 +57,12 @@ enum {
   GH_SHAPE_BOX = 0,      /* Cuboid(half extents)            urdf.rs:18-25 */
   GH_SHAPE_BALL = 1,     /* Ball(radius)                    urdf.rs:51-53 */
   GH_SHAPE_CYLINDER = 2, /* 30-gon prism TriMesh, Z axis    urdf.rs:26-50 */
-  GH_SHAPE_MESH = 3      /* closed convex TriMesh           urdf.rs:54-71 */
+  GH_SHAPE_MESH = 3      /* TriMesh, a triangle soup        urdf.rs:54-71.
+                          * Distance to a TriMesh is the minimum over its triangles (a surface: a shape
+                          * enclosed by it without touching is at a positive distance).  A closed convex
+                          * mesh of <= 64 vertices is held as ONE shape (hull + that surface rule); any
+                          * other mesh becomes one shape per triangle, and those count towards the
+                          * capacities: 1023 robot shapes, 32767 obstacle shapes per scene. */
 };
 
 /* per-configuration result byte */

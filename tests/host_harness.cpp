@@ -14,9 +14,9 @@ static int run_pair(const gh_shape_desc* a, const gh_mesh_desc* ma, int nma, con
                     const gh_mesh_desc* mb, int nmb, double margin) {
   HostTables<T> H;
   BuildError err{0, ""};
-  ShapeDev<T> sa, sb;
-  if (!detail::flatten_shape<T>(*a, ma, nma, -1, H, sa, err)) return err.code;
-  if (!detail::flatten_shape<T>(*b, mb, nmb, -1, H, sb, err)) return err.code;
+  std::vector<ShapeDev<T>> pa, pb;  // a mesh that is not a closed convex polytope comes back as one piece per triangle
+  if (!detail::flatten_shape<T>(*a, ma, nma, -1, H, pa, err)) return err.code;
+  if (!detail::flatten_shape<T>(*b, mb, nmb, -1, H, pb, err)) return err.code;
   auto ref = [](const ShapeDev<T>& s) {
     ShapeRef<T> r;
     r.kind = s.kind; r.half = {s.half[0], s.half[1], s.half[2]}; r.br = s.br;
@@ -24,20 +24,24 @@ static int run_pair(const gh_shape_desc* a, const gh_mesh_desc* ma, int nma, con
     r.pn = s.prism_n;
     return r;
   };
-  Pose<T> wa{{sa.lt[0], sa.lt[1], sa.lt[2]}, {sa.lq[0], sa.lq[1], sa.lq[2], sa.lq[3]}};
-  Pose<T> wb{{sb.lt[0], sb.lt[1], sb.lt[2]}, {sb.lq[0], sb.lq[1], sb.lq[2], sb.lq[3]}};
+  if (!(margin > 0)) return 0;
   LaneCounters lc{0, 0, 0, 0};
   const T* verts = H.verts.data();
   const T* planes = H.planes.data();
-  // bounding-sphere cull exactly as the kernels apply it
-  V3<T> ca = wa.t, cb = wb.t;
-  if (sa.kind == SK_MESH) ca = wa.t + qrot(wa.r, V3<T>{sa.bc[0], sa.bc[1], sa.bc[2]});
-  if (sb.kind == SK_MESH) cb = wb.t + qrot(wb.r, V3<T>{sb.bc[0], sb.bc[1], sb.bc[2]});
-  V3<T> d = ca - cb;
-  T rr = (sa.br + sb.br + T(margin)) * (T(1) + T(1e-4));
-  if (!(dot(d, d) < rr * rr)) return 0;
-  if (!(margin > 0)) return 0;
-  return pair_within<T, false>(ref(sa), wa, ref(sb), wb, verts, planes, T(margin), lc) ? 1 : 0;
+  for (const ShapeDev<T>& sa : pa)
+    for (const ShapeDev<T>& sb : pb) {  // the flags are an OR over the pieces' pairs
+      Pose<T> wa{{sa.lt[0], sa.lt[1], sa.lt[2]}, {sa.lq[0], sa.lq[1], sa.lq[2], sa.lq[3]}};
+      Pose<T> wb{{sb.lt[0], sb.lt[1], sb.lt[2]}, {sb.lq[0], sb.lq[1], sb.lq[2], sb.lq[3]}};
+      // bounding-sphere cull exactly as the kernels apply it
+      V3<T> ca = wa.t, cb = wb.t;
+      if (sa.kind == SK_MESH) ca = wa.t + qrot(wa.r, V3<T>{sa.bc[0], sa.bc[1], sa.bc[2]});
+      if (sb.kind == SK_MESH) cb = wb.t + qrot(wb.r, V3<T>{sb.bc[0], sb.bc[1], sb.bc[2]});
+      V3<T> d = ca - cb;
+      T rr = (sa.br + sb.br + T(margin)) * (T(1) + T(1e-4));
+      if (!(dot(d, d) < rr * rr)) continue;
+      if (pair_within<T, false>(ref(sa), wa, ref(sb), wb, verts, planes, T(margin), lc)) return 1;
+    }
+  return 0;
 }
 
 extern "C" int hh_pair_within(const gh_shape_desc* a, const gh_mesh_desc* ma, int nma, const gh_shape_desc* b,

@@ -198,14 +198,64 @@ def test_gpu_mesh_urdf_flags_match_oracle(tmp_path, hull, obstacles_robot, prec)
 
 
 @pytest.mark.gpu
-def test_gpu_open_mesh_is_refused_by_name(tmp_path, hull, sample_robot):
-    """A mesh outside the supported subset (closed, convex, <= 64 vertices) is refused when the scene is
-    built, with the reason — never approximated (DESIGN.md "Out of scope")."""
+@pytest.mark.parametrize("prec", [32, 64])
+def test_gpu_general_meshes_match_oracle(tmp_path, hull, sample_robot, obstacles_robot, prec):
+    """A mesh that is not a closed convex polytope — an open shell read from an OBJ file, a non-convex star, a
+    wavy sheet — is a triangle soup, as the reference's TriMesh is (urdf.rs:54-71): flags, and the per-obstacle
+    link masks of colliding_link_names, against the oracle, with such meshes as obstacles and as link geometry."""
     from gear_amd import engine
+    from oracle import binding as orc
+    from tests.parity import check_flags, certain
+    from tests.test_narrowphase_host import rand_soup
     verts, tris = hull
-    write_obj(tmp_path / "open.obj", verts, tris[:-1], quad=False)
+    write_obj(tmp_path / "open.obj", verts * 2.5, tris[:-3], quad=False)             # a hull with three faces missing
     v, t = urdf.load_obj_mesh(str(tmp_path / "open.obj"))
-    objects = D.Compound([D.ShapeSpec(D.GH_SHAPE_MESH, (0.0, 0.0, 0.0), vertices=v, triangles=t)])
-    w = W.Workload("open_mesh", sample_robot, objects, 0.01)
-    with pytest.raises(engine.GearHipError, match="not closed"):
+    rng = np.random.default_rng(17)
+    base = D.Compound.from_urdf_robot(obstacles_robot)
+    extra = [D.ShapeSpec(D.GH_SHAPE_MESH, (0.0, 0.0, 0.0), t=(0.5, 0.25, 0.5), q=urdf.quat_from_rpy(0.2, 0.4, 0.1), vertices=v, triangles=t)]
+    for kind, pos in (("star", (0.45, -0.3, 0.7)), ("sheet", (0.3, 0.3, 0.95)), ("star", (0.6, 0.0, 0.3))):
+        sv, st = rand_soup(rng, 0.18, kind)
+        extra.append(D.ShapeSpec(D.GH_SHAPE_MESH, (0.0, 0.0, 0.0), t=pos, q=urdf.quat_from_rpy(*rng.uniform(-1, 1, 3)), vertices=sv, triangles=st))
+    objects = D.Compound(list(base.shapes[:1]) + extra + list(base.shapes[1:]))      # soups between ordinary obstacles
+
+    def edit(model):                                                                  # ... and one as link geometry
+        sv, st = rand_soup(rng, 0.07, "sheet")
+        model.name_collision_model_map.setdefault("l_wrist_pitch", []).append(D.ShapeSpec(D.GH_SHAPE_MESH, (0.0, 0.0, 0.0), t=(0.0, 0.0, 0.05), vertices=sv, triangles=st))
+    w = W.Workload("general_meshes", sample_robot, objects, 0.01, self_pairs=[("root", "l_wrist_pitch"), ("l_shoulder_yaw", "l_wrist_pitch")],
+                   model_edit=edit)
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    ora64 = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64) if prec == 32 else None
+    q = w.configs(3000, seed=62, dtype=hip.dtype, overshoot=0.02)
+    both = D.GH_CHECK_ENV | D.GH_CHECK_SELF
+    rep, want = check_flags(f"general_meshes[f{prec}]", hip, ora, q, both, prec, ora64)
+    assert 0.05 < ((want & 1) > 0).mean() < 0.95
+    for path in (D.GH_PATH_FUSED, D.GH_PATH_PIPELINE, D.GH_PATH_PIPELINE | D.GH_PATH_NO_GRID, D.GH_PATH_SMALL):
+        assert (hip.check_batch(q, both | path) == hip.check_batch(q, both)).all(), hex(path)
+    # per (obstacle, node) bits, indexed by the CALLER's obstacles: a mesh's triangles are OR-ed
+    ql = q[:400]
+    _, band = ora.check(ql, both | D.GH_CHECK_NO_LIMITS, threads=16)
+    sure = certain(band, prec)
+    got, ref = hip.link_hits(ql, D.GH_CHECK_NO_LIMITS), ora.link_hits(ql, D.GH_CHECK_NO_LIMITS)
+    assert got.shape == ref.shape == (400, len(objects.shapes), 1)
+    assert (got[sure] == ref[sure]).all() and sure.mean() > 0.9
+    assert got[:, 1:5].any()                                                          # the soups are hit
+    assert (hip.self_hits(ql, D.GH_CHECK_NO_LIMITS)[sure] == ora.self_hits(ql, D.GH_CHECK_NO_LIMITS)[sure]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_capacity_is_refused_by_name(sample_robot):
+    """Every triangle of a general mesh is a device shape: the obstacle capacity (32767) counts them."""
+    from gear_amd import engine
+    n = 182                                                                           # 2 * 181 * 181 > 32767 triangles
+    xs = np.linspace(-1, 1, n)
+    verts = [[x, y, 0.1 * np.sin(3 * x) * np.cos(2 * y)] for x in xs for y in xs]
+    tris = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            a, b, c, d = i * n + j, i * n + j + 1, (i + 1) * n + j, (i + 1) * n + j + 1
+            tris += [[a, b, c], [b, d, c]]
+    objects = D.Compound([D.ShapeSpec(D.GH_SHAPE_MESH, (0.0, 0.0, 0.0), vertices=verts, triangles=tris)])
+    w = W.Workload("huge_mesh", sample_robot, objects, 0.01)
+    with pytest.raises(engine.GearHipError, match="32767 obstacle shapes"):
         engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)

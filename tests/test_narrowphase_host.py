@@ -117,11 +117,21 @@ def test_hollow_mesh_rule(prec):
     assert harness.pair_within(ShapeSpec.cylinder(0.05, 0.1), cyl, MARGIN, prec) == 0
 
 
-def test_nonconvex_mesh_rejected():
-    # an open mesh (one face missing) and a non-convex closed one
+def test_open_mesh_is_a_surface():
+    """An open mesh (one face of a tetrahedron missing) is no longer refused: it is its triangles.  A small ball at
+    the tetrahedron's centroid touches none of them — free — and one through a remaining face collides."""
     v = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
     open_tris = [(0, 1, 2), (0, 1, 3), (0, 2, 3)]
-    assert harness.pair_within(ShapeSpec.mesh(v, open_tris), ShapeSpec.ball(0.1, (5, 5, 5)), MARGIN, 64) == -5
+    mesh = ShapeSpec.mesh(v, open_tris)
+    assert harness.pair_within(mesh, ShapeSpec.ball(0.1, (5, 5, 5)), MARGIN, 64) == 0
+    assert harness.pair_within(mesh, ShapeSpec.ball(0.05, (0.25, 0.25, 0.25)), MARGIN, 64) == 0
+    assert harness.pair_within(mesh, ShapeSpec.ball(0.05, (0.25, 0.25, 0.03)), MARGIN, 64) == 1
+    assert harness.pair_within(mesh, ShapeSpec.ball(0.05, (0.4, 0.4, 0.4)), MARGIN, 64) == 0      # outside, beyond the missing face
+    for c in ((0.25, 0.25, 0.25), (0.25, 0.25, 0.03), (0.4, 0.4, 0.4)):
+        d, _ = orc.distance_bounds(mesh, ShapeSpec.ball(0.05, c), 64)
+        assert harness.pair_within(mesh, ShapeSpec.ball(0.05, c), MARGIN, 64) == (1 if d < MARGIN else 0)
+    bad = ShapeSpec.mesh(v, [(0, 1, 7)])
+    assert harness.pair_within(bad, ShapeSpec.ball(0.1, (5, 5, 5)), MARGIN, 64) == -1             # GH_ERR_INVALID
 
 
 @pytest.mark.parametrize("prec", [32, 64])
@@ -156,3 +166,66 @@ def test_gjk_iteration_cap_is_conservative(prec):
     assert orc.distance(cyl, ball, prec) > MARGIN + 1e-3
     assert harness.pair_within(cyl, ball, MARGIN, prec) == 0
     assert harness.pair_within(cyl, ball, MARGIN, prec, capped=True) == 1
+
+
+# ---- general triangle meshes (not closed, not convex): one device piece per triangle ---------------------
+def rand_soup(rng, scale, kind):
+    """kind 'open': a convex hull with a third of its faces removed; 'star': a non-convex closed star (the hull's
+    vertices pushed in and out alternately); 'sheet': a wavy open height field."""
+    if kind == "sheet":
+        n = 4
+        xs = np.linspace(-scale, scale, n)
+        verts = [[x, y, 0.3 * scale * math.sin(5 * x / scale) * math.cos(4 * y / scale)] for x in xs for y in xs]
+        tris = []
+        for i in range(n - 1):
+            for j in range(n - 1):
+                a, b, c, d = i * n + j, i * n + j + 1, (i + 1) * n + j, (i + 1) * n + j + 1
+                tris += [[a, b, c], [b, d, c]]
+        return verts, tris
+    v, t = rand_convex_mesh(rng, scale)
+    v = np.asarray(v)
+    if kind == "open":
+        keep = [tri for k, tri in enumerate(t) if k % 3 != 0]
+        return v.tolist(), keep
+    f = np.where(np.arange(len(v)) % 2 == 0, 1.0, 0.45)[:, None]
+    return (v * f).tolist(), t
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+@pytest.mark.parametrize("soup", ["open", "star", "sheet"])
+@pytest.mark.parametrize("other", ["box", "ball", "cyl", "mesh", "soup"])
+def test_general_meshes_match_oracle(soup, other, prec):
+    """The reference's TriMesh is a triangle soup: distance = min over triangles (urdf.rs:54-71).  The product
+    flattens a mesh that is not a closed convex polytope into one convex piece per triangle; the oracle walks the
+    triangles of the whole mesh."""
+    rng = np.random.default_rng(7000 + 10 * ["open", "star", "sheet"].index(soup) + ["box", "ball", "cyl", "mesh", "soup"].index(other))
+    n = 150 if other in ("mesh", "soup", "cyl") else 300
+    hits = near = uncert = bad = 0
+    for k in range(n):
+        v, t = rand_soup(rng, rng.uniform(0.08, 0.25), soup)
+        a = ShapeSpec.mesh(v, t, tuple(rng.uniform(-0.2, 0.2, 3)), quat_from_rpy(*rng.uniform(-math.pi, math.pi, 3)))
+        if other == "soup":
+            v2, t2 = rand_soup(rng, rng.uniform(0.08, 0.2), ("open", "star", "sheet")[k % 3])
+            b = ShapeSpec.mesh(v2, t2, tuple(rng.uniform(-0.2, 0.2, 3)), quat_from_rpy(*rng.uniform(-math.pi, math.pi, 3)))
+        else:
+            b = rand_shape(rng, other, 0.2)
+        if k % 2:
+            a, b = b, a
+        d, lo = orc.distance_bounds(a, b, prec)
+        got = harness.pair_within(a, b, MARGIN, prec)
+        assert got in (0, 1), got
+        want = 1 if d < MARGIN else 0
+        hits += want
+        if got != want:
+            if abs(d - MARGIN) <= BAND[prec]:
+                near += 1
+            elif want == 0 and lo - BAND[prec] < MARGIN:
+                uncert += 1
+            else:
+                bad += 1
+                print("MISMATCH", soup, other, prec, d, lo, got)
+    print(f"{soup}-{other} f{prec}: n={n} hits={hits} in-band={near} oracle-uncertified={uncert} bad={bad}")
+    assert bad == 0
+    if prec == 64:
+        assert uncert == 0
+    assert 0.03 * n < hits < 0.99 * n
