@@ -169,9 +169,8 @@ struct Carve {
 }  // namespace
 
 // ---- the pipeline's workspace: ONE pool per device, shared by every scene on it ---------------------
-// A planner holds a scene per (joint set, obstacle set); a workspace set is ~230 MB for a 1M-configuration
-// chunk of the metric scene (f32), four times that for mesh scenes, and up to four sets are in flight in one
-// call.  Scenes therefore own only their tables and staging buffers; the sets live here, grow to the
+// A planner holds a scene per (joint set, obstacle set); a workspace set is 0.69 GB for a 1M-configuration
+// chunk of the metric scene (f32: 660 B per configuration), and up to four sets are in flight in one call.  Scenes therefore own only their tables and staging buffers; the sets live here, grow to the
 // largest call seen on the device, and are freed when the device's last scene is destroyed.  Calls on
 // different scenes and streams may overlap in time, so a set carries the event of its last use: whoever
 // takes it next makes its stream wait for that event first (the enqueue itself runs under the pool's lock).
