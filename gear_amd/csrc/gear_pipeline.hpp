@@ -40,6 +40,7 @@ GD unsigned exact_class(int kind_a, int kind_b, bool self) {
 // self: kSelfItem | self shape pair << 6 | lane.
 constexpr unsigned kSelfItem = 0x80000000u;
 constexpr int kRing = 128;  // ring entries per wavefront (a push pass adds at most 64, a drain takes 64)
+constexpr int kHitList = 256;  // hit-list entries per wavefront (64 lanes x the four slots of half a cell block)
 
 struct PipeCounters {
   unsigned long long candidates;  // broadphase candidates tested (only with GH_COUNT_CANDIDATES in `what`)
@@ -131,7 +132,7 @@ template <class T> struct QLds {
 // k_sweep_n1
 //
 // LDS of a workgroup: [cull table (CLDS)] [robot part of SceneDev::hot] then per wavefront
-// [branch-point pose slots][centres of the shapes that are the earlier one of a self pair][ring][hit words].
+// [branch-point pose slots][centres of the shapes that are the earlier one of a self pair][ring][hit words][hit list].
 // (Those shapes' rotations wait in memory, PipeWs::fq: only the ~2 self pairs per configuration that survive
 // the centre cull need them, and 4 of 7 pose components out of LDS is what lets a fourth wavefront per SIMD
 // be resident.)
@@ -180,10 +181,11 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   T* const fq_wave = W.fq + wave * (size_t)S.n_first * kWave * 4;    // [n_first][64][4] rotations (memory)
   T* const ring = reinterpret_cast<T*>(my_lds + slot_bytes + first_bytes);  // [kRing][8]
   unsigned* const hits = reinterpret_cast<unsigned*>(ring + (size_t)kRing * 8);  // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self
+  unsigned* const hlist = hits + 8;  // [kHitList] the hits of half a cell block: owner lane << 16 | obstacle
   // this lane's row of the batch
-  QLds<T> qlds{reinterpret_cast<const T*>(hits + 8) + lane};  // Q_LDS: [n_cols][64] behind the hit words
+  QLds<T> qlds{reinterpret_cast<const T*>(hlist + kHitList) + lane};  // Q_LDS: [n_cols][64] behind the hit list
   if (QMODE == Q_LDS) {
-    T* w = reinterpret_cast<T*>(hits + 8) + lane;
+    T* w = reinterpret_cast<T*>(hlist + kHitList) + lane;
     for (int c = 0; c < S.n_cols; c++) w[c * kWave] = qmem[c];
   }
   auto qrow = [&]() -> decltype(auto) {
@@ -341,7 +343,6 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     }
     if (__ballot(blk != 0) == 0) continue;  // no lane of the wavefront has a list to look at
     const T rho = sh->br;
-    const unsigned code_base = ((unsigned)s << 6) | (unsigned)lane;
     // the shape's oriented box: half extents padded by the rounding of the transformed offset (a ball: the
     // cube around it).  The offset is rotated with the pose quaternion itself: a rotation matrix would be
     // nine more registers live across the drain below.
@@ -369,34 +370,61 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
         for (int j = 0; j < 8; j++) ncand += (unsigned)__popcll(__ballot(id[j] != sentinel));
       }
       if (env_done || GEAR_DBG(what, 0x400u)) h = 0;  // the configuration already collides: its flags are an OR
-      // one pass per hit of the busiest lane: second cull, then the survivors of the pass take ring slots
-      while (__ballot(h != 0) != 0) {
-        const bool cand = h != 0;
-        const unsigned z = cand ? (unsigned)__builtin_ctz(h) : 0u;
-        h &= h - 1u;  // 0 stays 0
-        // slot z of the block: 16 bits of one of its four words (a hit is never on a sentinel slot, so the
-        // raw words serve even in a chained block)
-        const unsigned wz = z < 4u ? (z < 2u ? w.x : w.y) : (z < 6u ? w.z : w.w);
-        const unsigned idz = cand ? (wz >> ((z & 1u) << 4)) & 0xffffu : sentinel;
-        bool pass = cand;
-        if (!GEAR_DBG(what, 0x200000u)) {
-          const Cull4<T> c = ocull[idz];
-          const T dx = c.x - ws.t.x, dy = c.y - ws.t.y, dz = c.z - ws.t.z;
-          // R^T d = d + w t' + u x t' with u = -(i, j, k), t' = 2 u x d
-          const T ui = -ws.r.i, uj = -ws.r.j, uk = -ws.r.k;
-          const T tx = T(2) * (uj * dz - uk * dy), ty = T(2) * (uk * dx - ui * dz), tz = T(2) * (ui * dy - uj * dx);
-          const T px = dx + ws.r.w * tx + (uj * tz - uk * ty), py = dy + ws.r.w * ty + (uk * tx - ui * tz), pz = dz + ws.r.w * tz + (ui * ty - uj * tx);
-          const T ex = t_max(t_abs(px) - hbx, T(0)), ey = t_max(t_abs(py) - hby, T(0)), ez = t_max(t_abs(pz) - hbz, T(0));
-          pass = cand && (ex * ex + ey * ey + ez * ez < c.r * c.r);
+      // The hits of the wavefront's 64 lanes (one or two per lane, unevenly spread) are made dense before the
+      // second cull: half a block at a time, every hit is listed as (owner lane, obstacle) in LDS, and the
+      // wavefront then takes the list 64 entries per pass, one hit per lane — the owner's shape pose comes over
+      // by lane shuffles.  (A loop of one pass per hit of the BUSIEST lane ran ~5 passes per shape at ~20 %
+      // lane use; this runs ~2.)
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const unsigned hh = (h >> (4 * half)) & 15u;
+        if (__ballot(hh != 0) == 0) continue;
+        unsigned tot = 0;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool on = ((hh >> j) & 1u) != 0;
+          const unsigned long long b = __ballot(on);
+          // (the index is taken from the block's words again: eight unpacked indices would be eight registers live
+          // across the narrow-phase site below)
+          if (on) hlist[tot + lane_rank(b)] = ((unsigned)lane << 16) | (((half ? (j < 2 ? w.z : w.w) : (j < 2 ? w.x : w.y)) >> ((j & 1) << 4)) & 0xffffu);
+          tot += (unsigned)__popcll(b);
         }
-        if (__ballot(pass) == 0) continue;
-        if (count >= (unsigned)kWave) {
-          drain();
-          if (env_done) { h = 0; pass = false; }  // decided meanwhile
+        wave_lds_sync();
+        for (unsigned p0 = 0; p0 < tot; p0 += (unsigned)kWave) {
+          const bool have = p0 + (unsigned)lane < tot;
+          unsigned e = hlist[have ? p0 + (unsigned)lane : 0u];
+          int src = (int)(e >> 16);
+          unsigned idz = have ? (e & 0xffffu) : sentinel;
+          Pose<T> sp{{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
+                     {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
+          bool pass = have;
+          if (!GEAR_DBG(what, 0x200000u)) {
+            const Cull4<T> c = ocull[idz];
+            const T dx = c.x - sp.t.x, dy = c.y - sp.t.y, dz = c.z - sp.t.z;
+            // R^T d = d + w t' + u x t' with u = -(i, j, k), t' = 2 u x d
+            const T ui = -sp.r.i, uj = -sp.r.j, uk = -sp.r.k;
+            const T tx = T(2) * (uj * dz - uk * dy), ty = T(2) * (uk * dx - ui * dz), tz = T(2) * (ui * dy - uj * dx);
+            const T px = dx + sp.r.w * tx + (uj * tz - uk * ty), py = dy + sp.r.w * ty + (uk * tx - ui * tz), pz = dz + sp.r.w * tz + (ui * ty - uj * tx);
+            const T ex = t_max(t_abs(px) - hbx, T(0)), ey = t_max(t_abs(py) - hby, T(0)), ez = t_max(t_abs(pz) - hbz, T(0));
+            pass = have && (ex * ex + ey * ey + ez * ez < c.r * c.r);
+          }
+          if (__ballot(pass) == 0) continue;
+          if (count >= (unsigned)kWave) {
+            drain();
+            // nothing of this pass but `pass` itself is kept across the narrow-phase site (it needs the registers):
+            // entry and pose are fetched again
+            e = hlist[have ? p0 + (unsigned)lane : 0u];
+            src = (int)(e >> 16);
+            idz = have ? (e & 0xffffu) : sentinel;
+            sp = {{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
+                  {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
+            pass = pass && ((hits[src >> 5] >> (src & 31)) & 1u) == 0;  // the owner was decided meanwhile
+          }
+          const unsigned long long pb = __ballot(pass);
+          if (pass) ItemIO<T>::store(ring + (size_t)((head + count + lane_rank(pb)) & (unsigned)(kRing - 1)) * 8,
+                                     (idz << 16) | ((unsigned)s << 6) | (unsigned)src, sp);
+          count += (unsigned)__popcll(pb);
         }
-        const unsigned long long pb = __ballot(pass);
-        if (pass) ItemIO<T>::store(ring + (size_t)((head + count + lane_rank(pb)) & (unsigned)(kRing - 1)) * 8, (idz << 16) | code_base, ws);
-        count += (unsigned)__popcll(pb);
       }
       blk = (cont && !env_done) ? (w.w & 0x7fffffffu) : 0u;
       more = __ballot(blk != 0) != 0;
