@@ -254,6 +254,7 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   if ((rc = upload(sc, H.sp_first_slot, &S.sp_first_slot))) return rc;
   if ((rc = upload(sc, H.sp_late_off, &S.sp_late_off))) return rc;
   if ((rc = upload(sc, H.sp_late, &S.sp_late))) return rc;
+  if ((rc = upload(sc, H.sp_late_rec, &S.sp_late_rec))) return rc;
   if ((rc = upload(sc, H.hot, &S.hot))) return rc;
   if ((rc = upload(sc, H.verts, &S.verts))) return rc;
   if ((rc = upload(sc, H.planes, &S.planes))) return rc;

@@ -205,7 +205,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   const int4* __restrict__ spairs4 = reinterpret_cast<const int4*>(S.spairs);
   const GEAR_CAS int32_t* sp_first_slot = to_cas(S.sp_first_slot);
   const GEAR_CAS int32_t* sp_late_off = to_cas(S.sp_late_off);
-  const GEAR_CAS int32_t* sp_late = to_cas(S.sp_late);
+  const GEAR_CAS SpLate<T>* sp_late_rec = to_cas(S.sp_late_rec);
   const GEAR_CAS GridDev<T>* grids = to_cas(S.grids);
   const GEAR_CAS int32_t* shape_grid = to_cas(S.shape_grid);
   const uint4* __restrict__ blocks = reinterpret_cast<const uint4*>(S.cell_blk);
@@ -306,15 +306,16 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     if (do_self) {
       // self shape pairs whose later shape is s: its pose is live, the other one's centre is read from LDS
       for (int e = sp_late_off[s]; e < sp_late_off[s + 1]; e++) {
-        const int p = sp_late[e];
-        const int fs = V.spairs[4 * p + 3];  // LDS slot of the pair's earlier shape, -1: the pair is (s, s)
+        const GEAR_CAS SpLate<T>* lr = sp_late_rec + e;  // one 16-byte scalar load: pair, LDS slot of its earlier shape, radius sum
+        const int p = lr->p;
+        const int fs = lr->fs;  // -1: the pair is (s, s)
         V3<T> oc = ws.t;
         if (fs >= 0) {
           const T* b = first_base + (size_t)fs * 3 * kWave + lane;
           oc = {b[0], b[kWave], b[2 * kWave]};
         }
         const V3<T> d = ws.t - oc;  // (c1 - c2) or (c2 - c1): the squares are the same
-        const T rr = V.spair_r[p];
+        const T rr = lr->rr;
         const bool hit = push_ok && !self_done && dot(d, d) < rr * rr && !GEAR_DBG(what, 0x400u);
         const unsigned long long hb = __ballot(hit);
         if (hb == 0) continue;

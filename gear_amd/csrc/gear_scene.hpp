@@ -38,6 +38,7 @@ struct HostTables {
   std::vector<int32_t> shape_grid;
   std::vector<uint32_t> cell_blk;  // [n_blocks][4], see SceneDev::cell_blk
   std::vector<int32_t> sp_first_slot, sp_late_off, sp_late;  // see SceneDev
+  std::vector<SpLate<T>> sp_late_rec;
   std::vector<T> hot;                                        // see SceneDev::hot
   int n_first = 0;
   int n_slots = 0;
@@ -552,6 +553,13 @@ inline bool build_tables(const gh_robot_desc& r, const gh_obstacle_desc& o, doub
     for (size_t s = 0; s < L; s++) {
       H.sp_late.insert(H.sp_late.end(), by_late[s].begin(), by_late[s].end());
       H.sp_late_off.push_back((int32_t)H.sp_late.size());
+    }
+    for (int32_t p : H.sp_late) {
+      SpLate<T> r{};
+      r.p = p;
+      r.fs = H.spairs[4 * (size_t)p + 3];
+      r.rr = H.spair_r[(size_t)p];
+      H.sp_late_rec.push_back(r);
     }
   }
   return true;

@@ -73,6 +73,12 @@ struct GridDev {
   int32_t off_base;  // block index of this grid's cell (0,0,0) in cell_blk[] (nx*ny*nz head blocks)
 };
 
+// One self shape pair as the sweep meets it (at its later shape): the pair's index, the LDS slot of its earlier
+// shape (-1: both are the same shape) and the inflated radius sum — one 16-byte scalar load per pair test.
+template <class T> struct SpLate;
+template <> struct alignas(16) SpLate<float> { int32_t p, fs; float rr, pad; };
+template <> struct alignas(16) SpLate<double> { int32_t p, fs; double rr; };
+
 struct CountersDev {
   unsigned long long configs, pairs, cull_pass, sat_tests, exact_tests, exact_iters, r0, r1;
 };
@@ -105,6 +111,7 @@ struct SceneDev {
   const int32_t* sp_first_slot;  // [n_shapes] LDS pose slot of a shape that is the earlier one of some pair, else -1
   const int32_t* sp_late_off;    // [n_shapes + 1] CSR offsets into sp_late
   const int32_t* sp_late;        // [n_spairs] self shape pair indices
+  const SpLate<T>* sp_late_rec;  // [n_spairs] the same entries with what the sweep needs of each pair
   // what stage 1 of the narrow phase needs of a shape, compact: robot shapes {half[3], kind} (4 T each),
   // then obstacle shapes {t[3], kind | q[4] | half[3], 0} (12 T each); kinds stored as T(kind)
   const T* hot;                  // [n_shapes * 4 + n_obs * 12]
