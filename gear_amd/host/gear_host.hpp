@@ -23,6 +23,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -732,6 +733,7 @@ struct Stats {
   uint64_t consumed = 0;      // samples the sequential algorithm would have evaluated
   uint64_t iterations = 0;    // dual_rrt_connect loop iterations
   uint64_t shortcuts = 0;     // smoothing shortcuts applied
+  uint64_t eval_ns = 0;       // wall time spent inside the evaluator (staging, launch, synchronisation)
 };
 
 // Evaluates lines of samples: `q` holds all samples row-major, line e = rows [off[e], off[e+1]).
@@ -1156,7 +1158,10 @@ template <class N> class JointPathPlanner {
     if (!feasible(start_angles)) throw collision(CollisionPart::Start);
     if (!feasible(goal_angles)) throw collision(CollisionPart::End);
     rrt::LineEval<N> eval = [&](const std::vector<N>& q, const std::vector<uint32_t>& off) {
-      return first_infeasible(using_joints, q, off, objects, with_self);
+      const auto t0 = std::chrono::steady_clock::now();
+      auto bad = first_infeasible(using_joints, q, off, objects, with_self);
+      stats.eval_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      return bad;
     };
     std::vector<std::vector<N>> path;
     try {

@@ -25,4 +25,4 @@ for spec in (True, False, True, False):
     dt = time.perf_counter() - t0
     st = dict(pl.last_stats)
     print(f"speculative={spec} plan {dt * 1e3:8.1f} ms  way points {len(path)}  gpu calls {st['gpu_calls']}  "
-          f"{dt * 1e6 / max(st['gpu_calls'], 1):6.1f} us per call  {st}", flush=True)
+          f"{dt * 1e6 / max(st['gpu_calls'], 1):6.1f} us per call, of which {st['eval_ns'] / 1e3 / max(st['gpu_calls'], 1):6.1f} us inside the evaluator  {st}", flush=True)
