@@ -3,7 +3,7 @@ stages switched off by `what` bits (WRONG flags on purpose; the product build ig
 0x100 queued items dropped (no narrow phase) | 0x200 nothing queued (culls still run) | 0x400 no broadphase |
 0x800 no FK walk (P1).  usage: GEAR_HIP_LIB=<ablate build> python tools/ablate_small.py [sizes]"""
 import sys, os, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from gear_amd import engine, workloads as W
 import bench
 w = W.metric_workload()

@@ -1,7 +1,7 @@
 """Latency of small batches (RRT lines), device buffers, back-to-back calls on one stream.
 usage: small_batch.py [path bits: 0 default, 0x20 k_small, 0x1000 fused, 0x2000 pipeline] [sizes] [precision]"""
 import sys, os, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from gear_amd import engine, workloads as W
 import bench
 w = W.metric_workload()
