@@ -112,7 +112,8 @@ struct Knobs {
   bool n2_hist = false;                 // GEAR_HIP_N2_HIST: histogram of GJK iterations (profiling)
   int n2_tile = 16;                     // GEAR_HIP_N2_TILE: sweep wavefronts per exact-stage workgroup (8, 16, 32)
   bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
-  size_t small_max = 8192;              // GEAR_HIP_SMALL_MAX: batches up to this size take k_small (0: never)
+  size_t small_max = 16384;             // GEAR_HIP_SMALL_MAX: batches up to this size take k_small (0: never); f64 scenes: 3/8 of it
+                                        // (measured crossovers with the pipeline: 18-60 k configurations in f32 on four scenes, ~7 k in f64)
   unsigned small_qcap = 1024;           // GEAR_HIP_SMALL_QCAP: item queue entries of a k_small workgroup (tests shrink it)
   static Knobs from_env() {
     Knobs k;
@@ -130,7 +131,7 @@ struct Knobs {
     k.n2_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;
     k.n2_tile = (int)num("GEAR_HIP_N2_TILE", 16);
     k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
-    k.small_max = (size_t)std::max<long long>(0, num("GEAR_HIP_SMALL_MAX", 8192));
+    k.small_max = (size_t)std::max<long long>(0, num("GEAR_HIP_SMALL_MAX", 16384));
     x = num("GEAR_HIP_SMALL_QCAP", 1024);
     k.small_qcap = (unsigned)(x < 1 ? 1 : x > 8192 ? 8192 : x);
     return k;
@@ -622,7 +623,7 @@ int small_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t
 bool small_takes(const gh_scene* sc, size_t n, uint32_t what, bool counted) {
   if (counted || !(what & 3u) || sc->L <= 0 || n == 0 || n >= (size_t(1) << 30) || sc->N > 4000) return false;  // (the walk packs slot indices in 12 bits)
   if (what & (kForceFused | kForcePipe | 0x8000u)) return false;
-  if (!(what & kForceSmall) && n > sc->knobs.small_max) return false;
+  if (!(what & kForceSmall) && n > (sc->precision == 32 ? sc->knobs.small_max : sc->knobs.small_max * 3 / 8)) return false;
   const size_t lds = sc->precision == 32 ? small_plan_of<float>(sc, sc->s32, n).lds : small_plan_of<double>(sc, sc->s64, n).lds;
   return lds <= kSmallLdsMax;
 }

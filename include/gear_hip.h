@@ -81,7 +81,7 @@ enum {
 enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2, GH_CHECK_NO_LIMITS = 0x10 };
 /* optional `what` bits that only choose HOW the batch is evaluated; the result
  * bytes are identical either way (tests/test_gpu_pipeline.py, tests/test_gpu_small.py).
- * Without them a call of up to 8192 configurations takes the single-launch
+ * Without them a call of up to 16384 configurations (6144 in f64) takes the single-launch
  * small-batch kernel (a configuration's work spread over many lanes: the RRT
  * lines of joint_path_planner.rs:168-188), larger ones the multi-kernel
  * pipeline; the fused kernel serves scenes whose tables do not fit either.

@@ -65,3 +65,18 @@ def test_bad_arguments_are_rejected_without_a_device():
     assert b"null" in lib.gh_last_error()
     assert lib.gh_check_batch(None, None, 4, 3, None) == -1
     assert lib.gh_scene_dof(None) == -1
+
+
+def test_constants_match_header():
+    """Every GH_* enumerator the Python binding names has the header's value."""
+    import re
+    from gear_amd import descriptors as D
+    text = open(os.path.join(ROOT, "include", "gear_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    header = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\b(GH_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))", text)}
+    assert {"GH_CHECK_ENV", "GH_CHECK_SELF", "GH_CHECK_NO_LIMITS", "GH_PATH_SMALL", "GH_PATH_FUSED", "GH_PATH_PIPELINE",
+            "GH_PATH_NO_GRID", "GH_COUNT_CANDIDATES", "GH_FLAG_ENV", "GH_FLAG_SELF", "GH_FLAG_LIMIT", "GH_SHAPE_MESH"} <= set(header)
+    named = {k: v for k, v in vars(D).items() if k.startswith("GH_") and isinstance(v, int)}
+    assert len(named) >= 12
+    for k, v in named.items():
+        assert header.get(k) == v, (k, v, header.get(k))

@@ -40,7 +40,7 @@ def test_small_equals_fused_and_pipeline(sample_robot, obstacles_robot, prec):
             assert (a == c).all(), (w.name, prec, what, int((a != c).sum()))
             assert (hip.check_batch(q, what | PIPE) == b).all()
         assert (a != 0).any() and (a == 0).any()
-        # ragged sizes around the workgroup's share of configurations, on the default path (<= 8192: k_small)
+        # ragged sizes around the workgroup's share of configurations, on the default path (k_small)
         for m in (1, 2, 3, 14, 15, 27, 28, 29, 63, 64, 65, 257, 1000):
             assert (hip.check_batch(q[:m], BOTH) == hip.check_batch(q[:m], BOTH | FUSED)).all(), (w.name, m)
 
