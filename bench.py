@@ -128,16 +128,20 @@ def cpu_baseline(w, precision, q_gpu=None, flags_gpu=None, seconds=12.0):
                       f"gear's path (oracle/), not the Rust crate"}
 
 
-def timed_steps(scene, q, flags, stream, steps, warmup):
-    """warmup + steps calls of gh_check_batch_dev on `stream`; returns (wall seconds, mean HIP-event ms per step)."""
-    for _ in range(warmup):
-        scene.check_batch_dev(q, flags, WHAT, stream)
+N_INPUTS = 3   # synthetic input batches used in rotation: no step re-reads the batch of the step before it
+
+
+def timed_steps(scene, qs, flags, stream, steps, warmup):
+    """warmup + steps calls of gh_check_batch_dev on `stream`, step k on input batch k % len(qs); returns
+    (wall seconds, mean HIP-event ms per step)."""
+    for k in range(warmup):
+        scene.check_batch_dev(qs[k % len(qs)], flags, WHAT, stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
         ev[k][0].record()
-        scene.check_batch_dev(q, flags, WHAT, stream)
+        scene.check_batch_dev(qs[k % len(qs)], flags, WHAT, stream)
         ev[k][1].record()
     torch.cuda.synchronize()
     return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -152,7 +156,8 @@ def side_measurement(w, precision, B, device, stream, steps, warmup, seed):
     ns = min(B, 1 << 16)
     counters = scene.check_batch_counted(q[:ns], flags[:ns], WHAT)
     fpc, mix = algorithmic_flops_per_config(w, counters)
-    wall, kms = timed_steps(scene, q, flags, stream, steps, warmup)
+    qs = [q] + [device_configs(w, B, seed + 7919 * j, dtype, device) for j in range(1, N_INPUTS)]
+    wall, kms = timed_steps(scene, qs, flags, stream, steps, warmup)
     rates = [float((flags & b).ne(0).float().mean()) for b in (1, 2, 4)]
     return {"workload": w.name, "dtype": "f32" if precision == 32 else "f64", "value": B * steps / wall, "unit": "configs/s",
             "batch": B, "ms_per_step": wall / steps * 1e3, "kernel_ms": kms,
@@ -197,6 +202,7 @@ def main():
     dtype = torch.float32 if args.precision == 32 else torch.float64
     B = args.batch
     q = device_configs(w, B, seed=1234 + rank, dtype=dtype, device=device)   # this rank's shard
+    qs = [q] + [device_configs(w, B, seed=1234 + rank + 7919 * j, dtype=dtype, device=device) for j in range(1, N_INPUTS)]
     flags = torch.zeros(B, dtype=torch.uint8, device=device)
     gathered = torch.zeros(B * world, dtype=torch.uint8, device=device) if world > 1 else None
     # a non-default torch stream: its handle is what the C ABI launches on, so torch.cuda.Event
@@ -229,7 +235,7 @@ def main():
     def step(k):
         nonlocal pending
         f = fbuf[k % len(fbuf)]
-        scene.check_batch_dev(q, f, WHAT, stream)
+        scene.check_batch_dev(qs[k % N_INPUTS], f, WHAT, stream)
         if world > 1:
             if pending is not None:
                 pending.wait()
@@ -249,7 +255,7 @@ def main():
     for k in range(args.steps):
         f = fbuf[k % len(fbuf)]
         ev[k][0].record()
-        scene.check_batch_dev(q, f, WHAT, stream)
+        scene.check_batch_dev(qs[k % N_INPUTS], f, WHAT, stream)
         ev[k][1].record()
         if world > 1:
             if pending is not None:
@@ -286,7 +292,7 @@ def main():
             "metric": "collision-checked configs/sec (whole node), 7-DOF arm vs 256 obstacles",
             "value": value, "unit": "configs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic (%d input batches in rotation)" % N_INPUTS,
             "config": {"workload": w.name, "dof": w.dof, "nodes": len(w.chain.nodes),
                        "robot_shapes": int(w.robot_keep.desc.n_shapes), "obstacles": int(w.obstacle_keep.desc.n_shapes),
                        "self_pairs": int(w.robot_keep.desc.n_pairs), "margin": w.margin,
