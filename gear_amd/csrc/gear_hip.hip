@@ -209,6 +209,8 @@ struct gh_scene {
   Knobs knobs;
   CountersDev* counters = nullptr;
   unsigned* small_done = nullptr;  // k_small's finished-workgroup ticket (behind `counters`; zero between calls)
+  PinBuf hseq;                     // the word a small host-buffer call's kernel stores its sequence number in when it is done
+  unsigned seq = 0;
   std::vector<gh_scene*> parts;  // gh_scene_create_multi: one scene per listed device; this object only routes
   size_t elem() const { return precision == 32 ? 4 : 8; }
 };
@@ -598,6 +600,8 @@ struct SmallEdges {  // gh_check_edges through k_small: the first-bad reduction 
   uint8_t bad_mask = 0;
   int32_t* first_bad = nullptr;
   uint8_t* flags_near = nullptr;  // device copy of the flags when the caller's are host memory
+  unsigned* notify = nullptr;     // host word (as the device addresses it) that receives `seq` when the call's results are in host memory
+  unsigned seq = 0;
 };
 constexpr size_t kSmallEdgesMax = 256;  // edges up to which the reduction rides in the k_small launch
 
@@ -614,7 +618,8 @@ int small_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint32_t
   const size_t groups = (n + (size_t)sp.C - 1) / (size_t)sp.C;
   hipLaunchKernelGGL((k_small<T>), dim3((unsigned)groups), dim3(kSmThreads), sp.lds, st, S, q, n, what, flags, sp.C, sp.qcap, all_blk, sp.cull_lds ? 1 : 0,
                      ed ? ed->edge_off : nullptr, ed ? (unsigned)ed->n_edges : 0u, ed ? (unsigned)ed->bad_mask : 0u,
-                     ed ? ed->first_bad : nullptr, ed ? ed->flags_near : nullptr, sc->small_done);
+                     ed ? ed->first_bad : nullptr, ed ? ed->flags_near : nullptr, sc->small_done, ed ? ed->notify : nullptr,
+                     ed ? ed->seq : 0u);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
@@ -626,6 +631,31 @@ bool small_takes(const gh_scene* sc, size_t n, uint32_t what, bool counted) {
   if (!(what & kForceSmall) && n > (sc->precision == 32 ? sc->knobs.small_max : sc->knobs.small_max * 3 / 8)) return false;
   const size_t lds = sc->precision == 32 ? small_plan_of<float>(sc, sc->s32, n).lds : small_plan_of<double>(sc, sc->s64, n).lds;
   return lds <= kSmallLdsMax;
+}
+
+// Waits until the kernel of a small host-buffer call has stored `seq` in the scene's host word: a short poll,
+// then the stream's own completion (which also reports a kernel that died).  The stream is left to drain by
+// itself: the next launch on it is ordered behind the kernel's last instructions anyway.
+// the scene's notify word: allocated on first use and ZEROED (pinned blocks are recycled: a word left behind by a
+// destroyed scene could otherwise equal this scene's first sequence number)
+int ensure_notify_word(gh_scene* sc) {
+  if (sc->hseq.p) return GH_OK;
+  int rc = sc->hseq.ensure(64);
+  if (rc) return rc;
+  std::memset(sc->hseq.p, 0, 64);
+  sc->seq = 0;
+  return GH_OK;
+}
+
+int wait_notified(gh_scene* sc, unsigned seq) {
+  const volatile unsigned* w = (const volatile unsigned*)sc->hseq.p;
+  for (int spin = 0; spin < 20000; spin++) {
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return GH_OK;
+    __builtin_ia32_pause();
+  }
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seq) return fail(GH_ERR_HIP, "internal: a small-batch kernel finished without reporting");
+  return GH_OK;
 }
 
 int check_dev(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, hipStream_t st, bool counted,
@@ -809,7 +839,7 @@ void gh_scene_destroy(gh_scene* sc) {
     for (void* p : sc->tables) (void)hipFree(p);
     if (sc->counters) (void)hipFree(sc->counters);
     sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
-    sc->hq.release(); sc->hflags.release(); sc->hedges.release(); sc->hfirst.release();
+    sc->hq.release(); sc->hflags.release(); sc->hedges.release(); sc->hfirst.release(); sc->hseq.release();
     for (int k = 1; k < kMaxSets; k++) {
       if (sc->aux[k]) { (void)hipStreamSynchronize(sc->aux[k]); (void)hipStreamDestroy(sc->aux[k]); }
       if (sc->ev_join[k]) (void)hipEventDestroy(sc->ev_join[k]);
@@ -883,10 +913,23 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
   int rc;
   size_t qb = n * sc->D * sc->elem();
   if (n <= kZeroCopyMax && sc->knobs.zero_copy) {
-    if ((rc = sc->hq.ensure(qb)) || (rc = sc->hflags.ensure(n))) return rc;
+    if ((rc = sc->hq.ensure(qb)) || (rc = sc->hflags.ensure(n)) || (rc = ensure_notify_word(sc))) return rc;
     std::memcpy(sc->hq.p, q, qb);
-    if ((rc = check_dev(sc, sc->hq.d, n, what, (uint8_t*)sc->hflags.d, sc->stream, false))) return rc;
-    GH_HIP(hipStreamSynchronize(sc->stream));
+    uint32_t w = what;
+#ifndef GEAR_HIP_ABLATE
+    w &= kWhatPublic;
+#endif
+    if (sc->margin > 0 && small_takes(sc, n, w, false)) {  // one launch; its last workgroup tells the host when the flags are in
+      SmallEdges ex;
+      ex.notify = (unsigned*)sc->hseq.d;
+      ex.seq = ++sc->seq;
+      rc = sc->precision == 32 ? small_dev<float>(sc, sc->s32, (const float*)sc->hq.d, n, w, (uint8_t*)sc->hflags.d, sc->stream, &ex)
+                               : small_dev<double>(sc, sc->s64, (const double*)sc->hq.d, n, w, (uint8_t*)sc->hflags.d, sc->stream, &ex);
+      if (rc || (rc = wait_notified(sc, ex.seq))) return rc;
+    } else {
+      if ((rc = check_dev(sc, sc->hq.d, n, what, (uint8_t*)sc->hflags.d, sc->stream, false))) return rc;
+      GH_HIP(hipStreamSynchronize(sc->stream));
+    }
     std::memcpy(flags, sc->hflags.p, n);
     return GH_OK;
   }
@@ -942,7 +985,8 @@ int gh_pipeline_last_stats(gh_scene* sc, uint64_t out[4]) {
 // flags of every sample + first flagged sample per edge; the caller holds the scene's Guard
 static int check_edges_locked(gh_scene* sc, const void* q_dev, const uint32_t* edge_off_dev, size_t n_edges,
                               size_t n_samples, uint32_t what, uint8_t bad_mask, uint8_t* flags_dev,
-                              int32_t* first_bad_dev, hipStream_t st, bool exclusive = false, uint8_t* flags_near = nullptr) {
+                              int32_t* first_bad_dev, hipStream_t st, bool exclusive = false, uint8_t* flags_near = nullptr,
+                              unsigned* notify = nullptr, unsigned seq = 0, bool* notified = nullptr) {
 #ifndef GEAR_HIP_ABLATE
   what &= kWhatPublic;
 #endif
@@ -951,6 +995,8 @@ static int check_edges_locked(gh_scene* sc, const void* q_dev, const uint32_t* e
   if (exclusive && n_edges > 0 && n_edges <= kSmallEdgesMax && sc->margin > 0 && small_takes(sc, n_samples, what, false)) {
     SmallEdges ed;
     ed.edge_off = edge_off_dev; ed.n_edges = n_edges; ed.bad_mask = bad_mask; ed.first_bad = first_bad_dev; ed.flags_near = flags_near;
+    ed.notify = notify; ed.seq = seq;
+    if (notified) *notified = notify != nullptr;
     return sc->precision == 32 ? small_dev<float>(sc, sc->s32, (const float*)q_dev, n_samples, what, flags_dev, st, &ed)
                                : small_dev<double>(sc, sc->s64, (const double*)q_dev, n_samples, what, flags_dev, st, &ed);
   }
@@ -1021,11 +1067,15 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
       return rc;
     if (qb) std::memcpy(sc->hq.p, q, qb);
     std::memcpy(sc->hedges.p, edge_off, (n_edges + 1) * 4);
-    if ((rc = sc->flags.ensure(kZeroCopyMax))) return rc;
+    if ((rc = sc->flags.ensure(kZeroCopyMax)) || (rc = ensure_notify_word(sc))) return rc;
+    bool notified = false;
+    const unsigned seq = ++sc->seq;
     if ((rc = check_edges_locked(sc, sc->hq.d, (const uint32_t*)sc->hedges.d, n_edges, n, what, bad_mask,
-                                 (uint8_t*)sc->hflags.d, (int32_t*)sc->hfirst.d, sc->stream, true, (uint8_t*)sc->flags.p)))
+                                 (uint8_t*)sc->hflags.d, (int32_t*)sc->hfirst.d, sc->stream, true, (uint8_t*)sc->flags.p,
+                                 (unsigned*)sc->hseq.d, seq, &notified)))
       return rc;
-    GH_HIP(hipStreamSynchronize(sc->stream));
+    if (notified) { if ((rc = wait_notified(sc, seq))) return rc; }
+    else GH_HIP(hipStreamSynchronize(sc->stream));
     if (n) std::memcpy(flags, sc->hflags.p, n);
     std::memcpy(first_bad, sc->hfirst.p, n_edges * 4);
     return GH_OK;

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(kSmThreads)
 k_small(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t* flags, int C, unsigned qcap, int all_blk,
         int cull_lds,
         const uint32_t* __restrict__ edge_off, unsigned n_edges, unsigned bad_mask, int32_t* __restrict__ first_bad,
-        uint8_t* flags_near, unsigned* done) {
+        uint8_t* flags_near, unsigned* done, unsigned* notify, unsigned notify_seq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
   const int tid = threadIdx.x;
@@ -411,10 +411,18 @@ k_small(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
     flags[c0 + (size_t)tid] = (uint8_t)out;
     if (flags_near) flags_near[c0 + (size_t)tid] = (uint8_t)out;
   }
-  if (first_bad == nullptr) return;
+  if (first_bad == nullptr && notify == nullptr) return;
 
-  // ---- P5 (gh_check_edges): the last workgroup to get here reduces the flags of the whole call ------------
-  __threadfence();  // this workgroup's flag bytes are visible device-wide before its ticket is
+  // ---- P5: the last workgroup to get here (a ticket from *done) finishes the call ---------------------------
+  // gh_check_edges: it reduces the flags of the whole call to every edge's first flagged sample.
+  // notify (host-buffer calls, whose flags and first-bad indices go straight to pinned host memory): when
+  // everything is written and visible to the host it stores the call's sequence number in a host word that
+  // the calling thread polls — that costs 5 us less per call than waiting for the stream's completion signal
+  // (tools/sync_vs_poll.hip).  Ordering: every workgroup fences its flag bytes at SYSTEM scope before taking
+  // its ticket; the last one fences again after the ticket (and after the reduction's stores) and only then
+  // releases the sequence number.
+  if (notify) __threadfence_system();
+  else __threadfence();  // this workgroup's flag bytes are visible device-wide before its ticket is
   __syncthreads();
   if (tid == 0) {
     const unsigned ticket = atomicAdd(done, 1u);
@@ -422,31 +430,39 @@ k_small(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
   }
   __syncthreads();
   if (qfill[1] == 0) return;
-  __threadfence();  // ... and the other workgroups' are visible here
-  const volatile uint8_t* vf = flags_near ? flags_near : flags;
-  if ((size_t)n_edges * 16 <= n) {
-    // long edges (connect lines): a wavefront per edge, 64 samples per step, stop at the first step with a hit
-    const unsigned lane = (unsigned)tid & 63u;
-    for (unsigned e = (unsigned)tid >> 6; e < n_edges; e += kSmThreads / 64) {
-      const unsigned lo = edge_off[e], hi = edge_off[e + 1];
-      int32_t fb = -1;
-      for (unsigned k0 = lo; k0 < hi; k0 += 64) {
-        const unsigned k = k0 + lane;
-        const unsigned long long hb = __ballot(k < hi && (vf[k] & bad_mask) != 0);
-        if (hb != 0) { fb = (int32_t)(k0 - lo) + __builtin_ctzll(hb); break; }
+  if (notify) __threadfence_system();
+  else __threadfence();  // ... and the other workgroups' are visible here
+  if (first_bad != nullptr) {
+    const volatile uint8_t* vf = flags_near ? flags_near : flags;
+    if ((size_t)n_edges * 16 <= n) {
+      // long edges (connect lines): a wavefront per edge, 64 samples per step, stop at the first step with a hit
+      const unsigned lane = (unsigned)tid & 63u;
+      for (unsigned e = (unsigned)tid >> 6; e < n_edges; e += kSmThreads / 64) {
+        const unsigned lo = edge_off[e], hi = edge_off[e + 1];
+        int32_t fb = -1;
+        for (unsigned k0 = lo; k0 < hi; k0 += 64) {
+          const unsigned k = k0 + lane;
+          const unsigned long long hb = __ballot(k < hi && (vf[k] & bad_mask) != 0);
+          if (hb != 0) { fb = (int32_t)(k0 - lo) + __builtin_ctzll(hb); break; }
+        }
+        if (lane == 0) first_bad[e] = fb;
       }
-      if (lane == 0) first_bad[e] = fb;
-    }
-  } else {
-    for (unsigned e = (unsigned)tid; e < n_edges; e += kSmThreads) {
-      const unsigned lo = edge_off[e], hi = edge_off[e + 1];
-      int32_t fb = -1;
-      for (unsigned k = lo; k < hi; k++)
-        if (vf[k] & bad_mask) { fb = (int32_t)(k - lo); break; }
-      first_bad[e] = fb;
+    } else {
+      for (unsigned e = (unsigned)tid; e < n_edges; e += kSmThreads) {
+        const unsigned lo = edge_off[e], hi = edge_off[e + 1];
+        int32_t fb = -1;
+        for (unsigned k = lo; k < hi; k++)
+          if (vf[k] & bad_mask) { fb = (int32_t)(k - lo); break; }
+        first_bad[e] = fb;
+      }
     }
   }
   if (tid == 0) *done = 0u;  // ready for the next call
+  if (notify) {
+    __threadfence_system();  // every lane's first-bad stores have reached the host's memory
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(notify, notify_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 #undef GEAR_SMALL_STAMP

@@ -98,3 +98,30 @@ def test_small_edges_first_bad(prec):
     f0, b0 = hip.check_edges(qe.astype(hip.dtype), off2, D.GH_CHECK_ENV | FUSED, bad)
     f1, b1 = hip.check_edges(qe.astype(hip.dtype), off2, D.GH_CHECK_ENV, bad)
     assert (f0 == f1).all() and (b0 == b1).all() and (b1[[1, 3, 4, 9]] == -1).all()
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_small_host_calls_report_complete_results(prec):
+    """Host-buffer calls of up to 4096 samples do not wait for the stream: the kernel's last workgroup stores the
+    call's sequence number in a host word once every flag byte and first-bad index is in host memory, and the
+    caller polls that word.  Thousands of calls of changing size and content, each against bytes computed
+    beforehand through the fused path (which synchronises the stream): a result read too early would show the
+    previous call's bytes."""
+    w = W.metric_workload()
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    rng = np.random.default_rng(91)
+    bad = D.GH_FLAG_ENV | D.GH_FLAG_LIMIT
+    pool = []
+    for k in range(24):
+        n = int(rng.choice([1, 2, 5, 33, 64, 200, 777, 1500, 4096]))
+        q = w.configs(n, seed=900 + k, dtype=hip.dtype, overshoot=0.02)
+        qe, off = w.edges(int(rng.integers(1, 40)), seed=950 + k, min_len=1, max_len=40)
+        qe = qe.astype(hip.dtype)
+        pool.append((q, hip.check_batch(q, BOTH | FUSED), qe, off, hip.check_edges(qe, off, D.GH_CHECK_ENV | FUSED, bad)))
+    for it in range(2500):
+        q, want, qe, off, (wf, wb) = pool[int(rng.integers(len(pool)))]
+        if it % 2:
+            assert (hip.check_batch(q, BOTH) == want).all(), it
+        else:
+            f, b = hip.check_edges(qe, off, D.GH_CHECK_ENV, bad)
+            assert (f == wf).all() and (b == wb).all(), it
