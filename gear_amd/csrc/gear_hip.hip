@@ -607,7 +607,7 @@ constexpr size_t kSmallEdgesMax = 256;  // edges up to which the reduction rides
 
 template <class T>
 SmallPlan small_plan_of(const gh_scene* sc, const SceneDev<T>& S, size_t n) {
-  return plan_small<T>(S.n_nodes, S.n_shapes, S.n_spairs, S.n_limits, S.n_slots, S.n_obs, sc->knobs.small_qcap, n);
+  return plan_small<T>(S.n_nodes, S.n_shapes, S.n_spairs, S.n_limits, S.n_slots, S.n_obs, S.n_cols, sc->knobs.small_qcap, n);
 }
 
 template <class T>

@@ -72,7 +72,7 @@ constexpr size_t kSmGroupsTarget = 512;  // two workgroups per compute unit are 
 constexpr int kSmCullLdsMax = 1024;  // obstacles (+ the dummy) up to which the cull table is copied into LDS
 
 template <class T> inline SmallPlan plan_small(int n_nodes, int n_shapes, int n_spairs, int n_limits, int n_slots, int n_obs,
-                                               unsigned qcap, size_t n) {
+                                               int n_cols, unsigned qcap, size_t n) {
   SmallPlan p;
   const int fine = std::max({kSmSlotLanes * n_shapes + n_spairs, n_nodes + n_limits, 1});
   const int coarse = std::max({n_shapes + n_spairs, n_nodes + n_limits, 1});
@@ -83,7 +83,7 @@ template <class T> inline SmallPlan plan_small(int n_nodes, int n_shapes, int n_
   p.cull_lds = n_obs + 1 <= kSmCullLdsMax;
   const size_t poses = (size_t)(n_slots + n_nodes) * 8 * p.C * sizeof(T);
   p.lds = (poses + 15) / 16 * 16 + ((size_t)(2 * kSmMaxC + 4 + 2 * qcap + n_nodes) * 4 + 15) / 16 * 16 +
-          (p.cull_lds ? (size_t)(n_obs + 1) * 4 * sizeof(T) : 0);
+          (p.cull_lds ? (size_t)(n_obs + 1) * 4 * sizeof(T) : 0) + (size_t)p.C * (size_t)n_cols * sizeof(T);
   return p;
 }
 
@@ -117,6 +117,7 @@ k_small(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
   unsigned* const xqueue = queue + qcap;                                      // [qcap] items stage 1 could not decide
   unsigned* const nmeta = xqueue + qcap;                                      // [N] what the walk needs of a node, packed
   Quad<T>* const lcull = reinterpret_cast<Quad<T>*>(gear_lds + t_bytes + ((size_t)(2 * kSmMaxC + 4 + 2 * qcap + N) * 4 + 15) / 16 * 16);  // [n_obs + 1]
+  T* const qs = reinterpret_cast<T*>(lcull + (cull_lds ? S.n_obs + 1 : 0));  // [C][n_cols] this workgroup's rows of the batch
 
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const bool do_self = (what & 2u) && S.n_spairs > 0;
@@ -181,39 +182,56 @@ k_small(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
 #define GEAR_SMALL_STAMP() do { } while (0)
 #endif
   GEAR_SMALL_STAMP();
+  // P0's own inputs: the node (or limit) record of this lane's first unit is requested now, and the workgroup's
+  // rows of the batch go to LDS with one coalesced read — the joint value then costs P0 no second memory trip
+  // behind the record that names its column
+  struct NodeUnit { V3<T> ot, axis; Q4<T> oq; T mult, off, const_pos; int jt, col, direct; unsigned meta; };
+  struct LimUnit { T mult, off, lo, hi; int col, direct; };
+  auto load_node = [&](int k) {
+    const NodeDev<T>* nd = S.nodes + k;
+    NodeUnit u;
+    u.ot = {nd->ot[0], nd->ot[1], nd->ot[2]};
+    u.axis = {nd->axis[0], nd->axis[1], nd->axis[2]};
+    u.oq = {nd->oq[0], nd->oq[1], nd->oq[2], nd->oq[3]};
+    u.mult = nd->mult; u.off = nd->off; u.const_pos = nd->const_pos;
+    u.jt = nd->joint_type; u.col = nd->col; u.direct = nd->direct;
+    // parent slot + 2 | (save slot + 1) << 12 | owns shapes << 31: read back by the walk from LDS, whose loads
+    // complete in order (a scalar load of the node record would make every wait a wait for everything)
+    u.meta = (unsigned)(nd->parent_slot + 2) | ((unsigned)(nd->save_slot + 1) << 12) | (nd->shape_end > nd->shape_begin ? 0x80000000u : 0u);
+    return u;
+  };
+  auto load_lim = [&](int l) {
+    const LimitDev<T>* lim = S.limits + l;
+    return LimUnit{lim->mult, lim->off, lim->lo, lim->hi, lim->col, lim->direct};
+  };
+  const int n_loc = (do_env || do_self) ? Cl * N : 0;
+  const int n_lim = do_limits ? Cl * S.n_limits : 0;
+  NodeUnit nu0{};
+  LimUnit lu0{};
+  if (tid < n_loc) nu0 = load_node(tid / Cl);
+  else if (tid < n_loc + n_lim) lu0 = load_lim((tid - n_loc) / Cl);
+  for (int u = tid; u < Cl * S.n_cols; u += kSmThreads) qs[u] = q[c0 * (size_t)S.n_cols + (size_t)u];
   if (tid < kSmMaxC) { cflag[tid] = 0; cbad[tid] = 0; }
   if (tid == 0) { qfill[0] = 0; qfill[2] = 0; }
   __syncthreads();
 
   // ---- P0: every node's transform relative to its parent; every limit ------------------------------------
-  {
-    const int n_loc = (do_env || do_self) ? Cl * N : 0;
-    const int n_lim = do_limits ? Cl * S.n_limits : 0;
-    for (int u = tid; u < n_loc + n_lim; u += kSmThreads) {
-      if (u < n_loc) {
-        const int c = u % Cl, k = u / Cl;
-        const NodeDev<T>* nd = S.nodes + k;
-        const T* qrow = q + (c0 + (size_t)c) * (size_t)S.n_cols;
-        T pos = nd->const_pos;  // node_position, with a lane-varying node
-        const int col = nd->col;
-        if (col >= 0) pos = joint_value(qrow[col], nd->direct, nd->mult, nd->off);
-        const V3<T> ot{nd->ot[0], nd->ot[1], nd->ot[2]}, axis{nd->axis[0], nd->axis[1], nd->axis[2]};
-        const Q4<T> oq{nd->oq[0], nd->oq[1], nd->oq[2], nd->oq[3]};
-        T s = T(0), cs = T(1);
-        if (nd->joint_type == JT_ROT) t_sincos(pos / T(2), &s, &cs);
-        PoseRecs<T>{node_base, C, c}.put(k, fk_local_sc(ot, oq, axis, nd->joint_type, pos, s, cs));
-        // parent slot + 2 | (save slot + 1) << 12 | owns shapes << 31: read back by the walk from LDS, whose loads
-        // complete in order (a scalar load of the node record would make every wait a wait for everything)
-        if (c == 0) nmeta[k] = (unsigned)(nd->parent_slot + 2) | ((unsigned)(nd->save_slot + 1) << 12) |
-                               (nd->shape_end > nd->shape_begin ? 0x80000000u : 0u);
-      } else {
-        const int v = u - n_loc;
-        const int c = v % Cl, l = v / Cl;
-        const LimitDev<T>* lim = S.limits + l;
-        const T* qrow = q + (c0 + (size_t)c) * (size_t)S.n_cols;
-        const T val = joint_value(qrow[lim->col], lim->direct, lim->mult, lim->off);
-        if (!(val <= lim->hi && val >= lim->lo)) cbad[c] = 1u;  // Range::is_valid, as limits_ok spells it
-      }
+  for (int u = tid; u < n_loc + n_lim; u += kSmThreads) {
+    if (u < n_loc) {
+      const int c = u % Cl, k = u / Cl;
+      const NodeUnit nd = u == tid ? nu0 : load_node(k);
+      T pos = nd.const_pos;  // node_position, with a lane-varying node
+      if (nd.col >= 0) pos = joint_value(qs[c * S.n_cols + nd.col], nd.direct, nd.mult, nd.off);
+      T s = T(0), cs = T(1);
+      if (nd.jt == JT_ROT) t_sincos(pos / T(2), &s, &cs);
+      PoseRecs<T>{node_base, C, c}.put(k, fk_local_sc(nd.ot, nd.oq, nd.axis, nd.jt, pos, s, cs));
+      if (c == 0) nmeta[k] = nd.meta;
+    } else {
+      const int v = u - n_loc;
+      const int c = v % Cl, l = v / Cl;
+      const LimUnit lim = u == tid ? lu0 : load_lim(l);
+      const T val = joint_value(qs[c * S.n_cols + lim.col], lim.direct, lim.mult, lim.off);
+      if (!(val <= lim.hi && val >= lim.lo)) cbad[c] = 1u;  // Range::is_valid, as limits_ok spells it
     }
   }
   if (cull_lds && do_env) {
