@@ -301,8 +301,8 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "kernel": "k_sweep_n1 (FK + broadphase + stage 1 of the narrow phase; dominant) + k_narrow2 (exact stage) + "
-                          "k_check (hit words -> flag bytes), one launch of each per 1M-config chunk, chunks rotating over "
-                          "4 streams from 3M configurations per call",
+                          "k_check (hit words -> flag bytes), one launch of each per chunk of at most 2M configurations (four 2M "
+                          "chunks per 8M step), chunks rotating over 4 streams from 3M configurations per call",
                 "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak, "traffic": traffic,
                 "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r02/pipeline_traffic.json)",
@@ -337,8 +337,12 @@ def main():
                                                  side_steps, 1, 1234)
         if world == 1 and not args.no_cpu_baseline:
             k = 0 if args.no_parity else 256
-            out["cpu_baseline"] = cpu_baseline(w, args.precision, q[:k].cpu().numpy() if k else None,
+            q_last = qs[(args.steps - 1) % N_INPUTS]   # the input batch of the step that wrote `flags`
+            out["cpu_baseline"] = cpu_baseline(w, args.precision, q_last[:k].cpu().numpy() if k else None,
                                                flags[:k].cpu().numpy() if k else None)
+            spot = out["cpu_baseline"]["gpu_parity_spot_check"]
+            if spot is not None and spot["outside"] != 0:
+                raise RuntimeError(f"bench: the timed step's flags differ from the oracle's outside the band: {spot}")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

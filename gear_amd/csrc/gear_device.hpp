@@ -86,21 +86,30 @@ GD double t_rint(double x) { return rint(x); }
 template <class T> GD T t_max(T a, T b) { return a > b ? a : b; }
 template <class T> GD T t_min(T a, T b) { return a < b ? a : b; }
 
-// ---- pose algebra: the formulas nalgebra uses for Isometry3 * Isometry3, kept
-// un-contracted so that node poses track the f32 reference to ~1 ulp ----------
+// ---- pose algebra: nalgebra's Isometry3 * Isometry3, every product-sum written as an explicit fma chain.
+// Explicit, not left to the compiler's contraction: the chain is then the same instruction sequence in every
+// kernel that walks a robot (k_small, the sweep, the fused kernel, k_fk), which is what makes their poses and
+// flags bit-identical, and it is 37 vector instructions per composition instead of the 61 of the separate
+// multiplies and adds the reference's f32 arithmetic performs.  The rounding differs from the reference's by
+// at most half an ulp per fused operation (the fused form is the more accurate one); DESIGN.md "Parity band"
+// has the measured pose deviation against the oracle, which keeps the reference's unfused sequence.
 #pragma clang fp contract(off)
+GD float t_fma(float a, float b, float c) { return fmaf(a, b, c); }
+GD double t_fma(double a, double b, double c) { return fma(a, b, c); }
 template <class T> GD Q4<T> qmul(Q4<T> a, Q4<T> b) {
-  return {a.w * b.i + a.i * b.w + a.j * b.k - a.k * b.j,
-          a.w * b.j - a.i * b.k + a.j * b.w + a.k * b.i,
-          a.w * b.k + a.i * b.j - a.j * b.i + a.k * b.w,
-          a.w * b.w - a.i * b.i - a.j * b.j - a.k * b.k};
+  return {t_fma(a.w, b.i, t_fma(a.i, b.w, t_fma(a.j, b.k, -(a.k * b.j)))),
+          t_fma(a.w, b.j, t_fma(-a.i, b.k, t_fma(a.j, b.w, a.k * b.i))),
+          t_fma(a.w, b.k, t_fma(a.i, b.j, t_fma(-a.j, b.i, a.k * b.w))),
+          t_fma(a.w, b.w, t_fma(-a.i, b.i, t_fma(-a.j, b.j, -(a.k * b.k))))};
 }
 template <class T> GD Q4<T> qconj(Q4<T> a) { return {-a.i, -a.j, -a.k, a.w}; }
+// v + w t + u x t with u = (i, j, k), t = 2 u x v
 template <class T> GD V3<T> qrot(Q4<T> q, V3<T> v) {
-  V3<T> qv{q.i, q.j, q.k};
-  V3<T> t = cross(qv, v) * T(2);
-  V3<T> c = cross(qv, t);
-  return t * q.w + c + v;
+  const T cx = t_fma(q.j, v.z, -(q.k * v.y)), cy = t_fma(q.k, v.x, -(q.i * v.z)), cz = t_fma(q.i, v.y, -(q.j * v.x));
+  const T tx = cx + cx, ty = cy + cy, tz = cz + cz;
+  return {t_fma(q.j, tz, t_fma(-q.k, ty, t_fma(q.w, tx, v.x))),
+          t_fma(q.k, tx, t_fma(-q.i, tz, t_fma(q.w, ty, v.y))),
+          t_fma(q.i, ty, t_fma(-q.j, tx, t_fma(q.w, tz, v.z)))};
 }
 template <class T> GD Pose<T> pose_mul(const Pose<T>& a, const Pose<T>& b) {
   V3<T> shift = qrot(a.r, b.t);

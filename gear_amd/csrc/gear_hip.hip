@@ -101,7 +101,7 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 // Tuning and test hooks.  Read from the environment ONCE, when a scene is created; no entry point looks
 // at the environment afterwards.
 struct Knobs {
-  size_t pipe_chunk = size_t(1) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass
+  size_t pipe_chunk = size_t(2) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass (at most; a call's chunks are equal)
   int pipe_streams = kMaxSets;          // GEAR_HIP_PIPE_STREAMS: 1 keeps every chunk on the caller's stream
   size_t exact_cap = 0;                 // GEAR_HIP_EXACT_CAP: exact entries per sweep wavefront (tests force re-checks with it)
   bool zero_copy = true;                // GEAR_HIP_ZERO_COPY=0: host-buffer calls always copy (measuring aid)
@@ -110,7 +110,7 @@ struct Knobs {
   int sweep_q = -1;                     // GEAR_HIP_SWEEP_Q: where the sweep keeps its batch row (0 memory, 2 LDS column; -1: chosen)
   bool n2_mlds = true;                  // GEAR_HIP_N2_MLDS=0: mesh table never in LDS
   bool n2_hist = false;                 // GEAR_HIP_N2_HIST: histogram of GJK iterations (profiling)
-  int n2_tile = 16;                     // GEAR_HIP_N2_TILE: sweep wavefronts per exact-stage workgroup (8, 16, 32)
+  int n2_tile = 0;                      // GEAR_HIP_N2_TILE: sweep wavefronts per exact-stage workgroup (8, 16, 32; 0: by chunk size)
   bool small_fused = false;             // GEAR_HIP_SMALL_FUSED: small batches through the fused kernel (measuring aid)
   size_t small_max = 16384;             // GEAR_HIP_SMALL_MAX: batches up to this size take k_small (0: never); f64 scenes: 3/8 of it
                                         // (measured crossovers with the pipeline: 18-60 k configurations in f32 on four scenes, ~7 k in f64)
@@ -129,7 +129,7 @@ struct Knobs {
     k.sweep_q = (int)num("GEAR_HIP_SWEEP_Q", -1);
     k.n2_mlds = num("GEAR_HIP_N2_MLDS", 1) != 0;
     k.n2_hist = getenv("GEAR_HIP_N2_HIST") != nullptr;
-    k.n2_tile = (int)num("GEAR_HIP_N2_TILE", 16);
+    k.n2_tile = (int)num("GEAR_HIP_N2_TILE", 0);
     k.small_fused = getenv("GEAR_HIP_SMALL_FUSED") != nullptr;
     k.small_max = (size_t)std::max<long long>(0, num("GEAR_HIP_SMALL_MAX", 16384));
     x = num("GEAR_HIP_SMALL_QCAP", 1024);
@@ -448,10 +448,13 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const SweepPlan sp = plan_sweep<T>(sc, S, do_env, do_self);
   if (!sp.ok) return fail(GH_ERR_TOO_LARGE, "internal: pipeline chosen for a scene whose sweep does not fit the LDS");
   const unsigned capw = sc->exact_cap;
-  // keep a chunk's exact arrays near 1 GiB at most
+  // keep a chunk's exact arrays under 3 GiB (they are reserved for the worst case and touched only where entries
+  // are written: capacity, not traffic; a 2M chunk of a scene with meshes and self pairs is 1.2 GiB in f32,
+  // 2.3 GiB in f64)
   const size_t entry_bytes = 8 + 8 * sizeof(T) * (do_self ? 2 : 1);
-  const size_t max_waves = std::max<size_t>((size_t(1) << 30) / (entry_bytes * capw), 64);
-  size_t chunk = std::min({(n + kWave - 1) / kWave * kWave, sc->knobs.pipe_chunk, max_waves * kWave, (size_t)1 << 27});
+  const size_t max_waves = std::max<size_t>((size_t(3) << 30) / (entry_bytes * capw), 64);
+  const size_t n_pad = (n + kWave - 1) / kWave * kWave;
+  const size_t chunk_max = std::min({n_pad, sc->knobs.pipe_chunk, max_waves * kWave, (size_t)1 << 27});
   // the fused kernel is the last stage (flag conversion + re-checks): it needs its own pose columns
   StorePlan plan = plan_store(sc, true);
   // Consecutive chunks are independent.  With several workspace sets they rotate over the caller's
@@ -459,9 +462,15 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   // cannot fill the chip, overlaps the next chunk's sweep.
   // Forking onto the scene's streams and joining back costs ~0.1 ms per call whatever the size, so only
   // batches of at least kMultiStreamMin configurations and two chunks rotate over several streams.
+  // Chunks of one call are equal (a short last chunk would leave its stream idle while the others finish), and a
+  // call that rotates over k streams is cut into a multiple of k chunks: 4 x 1M beats 2 x 2M, 4 x 2M beats 8 x 1M
+  // (MI355X, four scenes: profiles/r02/chunking.txt).
   int n_sets = (!plan.global && n >= kMultiStreamMin) ? sc->knobs.pipe_streams : 1;
-  n_sets = (int)std::min<size_t>(n_sets, (n + chunk - 1) / chunk);
   if (fixed) n_sets = 1;
+  size_t n_chunks = (n_pad + chunk_max - 1) / chunk_max;
+  if (n_sets > 1) n_chunks = (n_chunks + (size_t)n_sets - 1) / (size_t)n_sets * (size_t)n_sets;
+  const size_t chunk = std::min(chunk_max, ((n_pad + n_chunks - 1) / n_chunks + kWave - 1) / kWave * kWave);
+  n_sets = (int)std::min<size_t>(n_sets, (n + chunk - 1) / chunk);
   const bool two = n_sets > 1;
   const size_t waves = chunk / kWave;
   PipeWs<T> Ws[kMaxSets];
@@ -550,7 +559,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     {
       // the mesh pools (4-wide records) join the workgroup in LDS when they are at most 48 KB
       const size_t mesh_bytes = (size_t)(S.n_verts + S.n_planes) * 4 * sizeof(T);
-      const int tile = sc->knobs.n2_tile == 8 ? 8 : sc->knobs.n2_tile == 32 ? 32 : 16;
+      // ~1000 workgroups per launch: tiles of 32 sweep wavefronts from 1.5M-configuration chunks on (fewer, fuller
+      // workgroups; +1.5..3.5 % at 2M), tiles of 16 below (32 there: -5..-35 %, the launch no longer fills the chip)
+      const int tile = sc->knobs.n2_tile == 8 || sc->knobs.n2_tile == 16 || sc->knobs.n2_tile == 32 ? sc->knobs.n2_tile
+                       : (chunk >= (size_t(3) << 19) ? 32 : 16);
       const dim3 grid((n_sw + tile - 1) / tile), block(kN2Threads);
       const bool mlds = sc->knobs.n2_mlds && mesh_bytes > 0 && mesh_bytes <= 48 * 1024;
       auto go = [&](auto kern, size_t lds) { hipLaunchKernelGGL(kern, grid, block, lds, cs, S, what, W, n_sw); };

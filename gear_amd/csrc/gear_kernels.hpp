@@ -119,12 +119,55 @@ template <class T, class Q> __device__ __forceinline__ T node_position(const GEA
   return pos;
 }
 
+// A node's record as scalars.  Read field by field where each is needed, the record costs the walk four
+// dependent trips to the constant cache per node (parent slot -> column -> mimic terms -> origin); read as a
+// whole it is one.  (Requesting the NEXT node's record ahead of this node's arithmetic was measured too: the
+// 21 scalar registers it keeps live spill, -2 %.)
+template <class T> struct NodeRec {
+  V3<T> ot, axis;
+  Q4<T> oq;
+  T mult, off, const_pos;
+  int joint_type, col, direct, parent_slot, save_slot;
+};
+template <class T> __device__ __forceinline__ NodeRec<T> node_rec(const GEAR_CAS NodeDev<T>* nd) {
+  NodeRec<T> r;
+  r.ot = {nd->ot[0], nd->ot[1], nd->ot[2]};
+  r.oq = {nd->oq[0], nd->oq[1], nd->oq[2], nd->oq[3]};
+  r.axis = {nd->axis[0], nd->axis[1], nd->axis[2]};
+  r.mult = nd->mult; r.off = nd->off; r.const_pos = nd->const_pos;
+  r.joint_type = nd->joint_type; r.col = nd->col; r.direct = nd->direct;
+  r.parent_slot = nd->parent_slot; r.save_slot = nd->save_slot;
+  return r;
+}
+
+// world pose of a node given the walk state; updates `cur`
+template <class T, class Q>
+__device__ __forceinline__ void node_world_rec(const NodeRec<T>& r, const Q& qrow, const PoseStore<T>& st, Pose<T>& cur) {
+  Pose<T> parent = cur;
+  if (r.parent_slot == PARENT_IDENTITY) parent = {{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
+  else if (r.parent_slot >= 0) parent = st.get(r.parent_slot);
+  T pos = r.const_pos;
+  if (r.col >= 0) pos = joint_value(qrow[r.col], r.direct, r.mult, r.off);
+#ifdef GEAR_HIP_ABLATE_SINCOS  // attribution build (tools/attrib_sweep.sh): library sincosf instead of the f64-rounded one
+  T s = T(0), c = T(1);
+  if (r.joint_type == JT_ROT) { s = sin(pos / T(2)); c = cos(pos / T(2)); }
+  cur = fk_step_sc(parent, r.ot, r.oq, r.axis, r.joint_type, pos, s, c);
+#else
+  cur = fk_step(parent, r.ot, r.oq, r.axis, r.joint_type, pos);
+#endif
+  if (r.save_slot >= 0) st.put(r.save_slot, cur);
+}
+
 // world pose of node k given the walk state; updates `cur`.  SC: sin/cos of the half angle were
 // computed ahead of the walk and sit at sc[(2k) * 64 + lane], sc[(2k + 1) * 64 + lane].
 template <class T, bool SC = false, class Q = const T*>
 __device__ void node_world(const Views<T>& V, int k, const Q& qrow, const PoseStore<T>& st, Pose<T>& cur,
                            const T* sc = nullptr) {
   const GEAR_CAS NodeDev<T>* nd = V.nodes + k;
+  if (!SC) {
+    node_world_rec(node_rec<T>(nd), qrow, st, cur);
+    return;
+  }
   Pose<T> parent = cur;
   int ps = nd->parent_slot;
   if (ps == PARENT_IDENTITY) parent = {{T(0), T(0), T(0)}, {T(0), T(0), T(0), T(1)}};
@@ -132,19 +175,9 @@ __device__ void node_world(const Views<T>& V, int k, const Q& qrow, const PoseSt
   const T pos = node_position(nd, qrow);
   const V3<T> ot{nd->ot[0], nd->ot[1], nd->ot[2]}, axis{nd->axis[0], nd->axis[1], nd->axis[2]};
   const Q4<T> oq{nd->oq[0], nd->oq[1], nd->oq[2], nd->oq[3]};
-  if (SC) {
-    T s = T(0), c = T(1);
-    if (nd->joint_type == JT_ROT) { s = sc[(2 * k) * kWave]; c = sc[(2 * k + 1) * kWave]; }
-    cur = fk_step_sc(parent, ot, oq, axis, nd->joint_type, pos, s, c);
-  } else {
-#ifdef GEAR_HIP_ABLATE_SINCOS  // attribution build (tools/attrib_sweep.sh): library sincosf instead of the f64-rounded one
-    T s = T(0), c = T(1);
-    if (nd->joint_type == JT_ROT) { s = sin(pos / T(2)); c = cos(pos / T(2)); }
-    cur = fk_step_sc(parent, ot, oq, axis, nd->joint_type, pos, s, c);
-#else
-    cur = fk_step(parent, ot, oq, axis, nd->joint_type, pos);
-#endif
-  }
+  T s = T(0), c = T(1);
+  if (nd->joint_type == JT_ROT) { s = sc[(2 * k) * kWave]; c = sc[(2 * k + 1) * kWave]; }
+  cur = fk_step_sc(parent, ot, oq, axis, nd->joint_type, pos, s, c);
   int ss = nd->save_slot;
   if (ss >= 0) st.put(ss, cur);
 }
@@ -182,8 +215,6 @@ template <class T> __device__ PoseStore<T> make_store(T* gstore, size_t gstride,
 constexpr int kQCap = 448;  // stage-1 queue entries per wave
 constexpr int kGCap = 192;  // stage-2 (exact) queue entries per wave
 
-GD float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-GD double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 GD unsigned sign_bits(float t) { return __float_as_uint(t); }
 GD unsigned sign_bits(double t) { return (unsigned)__double2hiint(t); }
 

@@ -36,7 +36,7 @@ def test_config2_edge_validation_256_box_cyl(prec):
     # the field is dense (two thirds of random configurations collide): few whole edges stay free
     assert (first >= 0).sum() > 50 and (first < 0).sum() >= 20 and (first > 0).sum() > 50
     # oracle on a bounded subset of the edges
-    k = 24
+    k = 12
     sub_q, sub_off = q[:off[k]], off[:k + 1]
     wf, wb = ora.check_edges(sub_q, sub_off, D.GH_CHECK_ENV, bad_mask)
     allf, band = ora.check(sub_q, D.GH_CHECK_ENV, threads=16)
@@ -62,7 +62,7 @@ def test_config3_4096_obstacles_large_batch(prec):
     assert 0.05 < ((a & 1) != 0).mean() < 0.999
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, prec)
     ora64 = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64) if prec == 32 else None
-    check_flags(f"config3_4096_obstacles[f{prec}]", hip, ora, q[:640], BOTH | D.GH_PATH_PIPELINE, prec, ora64)
+    check_flags(f"config3_4096_obstacles[f{prec}]", hip, ora, q[:320], BOTH | D.GH_PATH_PIPELINE, prec, ora64)
 
 
 @pytest.mark.parametrize("prec", [32, 64])
