@@ -21,7 +21,7 @@ BOTH = D.GH_CHECK_ENV | D.GH_CHECK_SELF
 
 @pytest.mark.parametrize("prec", [32, 64])
 def test_metric_scene_multi_chunk_batch(prec):
-    """1M + 3 configurations of the metric scene: four chunks in flight, a ragged tail."""
+    """1M + 3 configurations of the metric scene: one call of the large-batch path with a ragged tail."""
     w = W.metric_workload()
     hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
     n = (1 << 20) + 3
@@ -118,6 +118,26 @@ def test_full_exact_regions_are_rechecked():
         assert (got == ref.check_batch(q, BOTH)).all()
         ref.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
         assert ref.pipeline_last_stats()["redo_waves"] == 0           # the default capacity is not reached here
+
+
+def test_chunks_over_several_streams():
+    """From 3M configurations on a call is cut into equal chunks, a multiple of the stream count, that rotate
+    over the caller's stream and the scene's own: four chunks of 768k by default; twelve ragged ones over three
+    streams and five over one with the knobs forced.  Every cut must give the fused kernel's bytes, and so must a
+    second call that finds the workspace sets used."""
+    w = W.metric_workload()
+    n = 3 * (1 << 20) + 5
+    q = w.configs(n, seed=37, overshoot=0.005)
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    ref = hip.check_batch(q, BOTH | D.GH_PATH_FUSED)
+    got = hip.check_batch(q, BOTH)
+    assert (got == ref).all()
+    assert (hip.check_batch(q, BOTH) == ref).all()
+    for env in ({"GEAR_HIP_PIPE_STREAMS": 3, "GEAR_HIP_PIPE_CHUNK": 300000},
+                {"GEAR_HIP_PIPE_STREAMS": 1, "GEAR_HIP_PIPE_CHUNK": 700000},
+                {"GEAR_HIP_PIPE_STREAMS": 2, "GEAR_HIP_N2_TILE": 8}):
+        other = _scene_with_env(w, 32, **env)
+        assert (other.check_batch(q, BOTH) == ref).all(), env
 
 
 def test_sweep_workgroup_shapes_agree():
