@@ -91,7 +91,7 @@ template <class T> GD T t_min(T a, T b) { return a < b ? a : b; }
 // kernel that walks a robot (k_small, the sweep, the fused kernel, k_fk), which is what makes their poses and
 // flags bit-identical, and it is 37 vector instructions per composition instead of the 61 of the separate
 // multiplies and adds the reference's f32 arithmetic performs.  The rounding differs from the reference's by
-// at most half an ulp per fused operation (the fused form is the more accurate one); DESIGN.md "Parity band"
+// at most half an ulp per fused operation (the fused form is the more accurate one); DESIGN.md "Pose algebra"
 // has the measured pose deviation against the oracle, which keeps the reference's unfused sequence.
 #pragma clang fp contract(off)
 GD float t_fma(float a, float b, float c) { return fmaf(a, b, c); }

@@ -89,6 +89,27 @@ def test_config2_64k_edges():
     assert (flags[sub] == hip.check_batch(q[sub], D.GH_CHECK_ENV | D.GH_PATH_FUSED)).all()
 
 
+def test_config3_full_shard_4096_obstacles():
+    """configs[3]: 64M configurations against 4096 mixed obstacles over 8 GPUs, i.e. 8M per GPU — one GPU's
+    shard in one call.  Size-independent properties: a permutation of the batch permutes the flags (other chunk
+    boundaries, other wave mates), a slice evaluated on its own gives the slice of the flags, and the fused
+    kernel's brute-force L x O sweep agrees on a sample spread over the whole shard."""
+    w = W.sawyer_workload(4096)
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    n = 1 << 23
+    q = w.configs(n, seed=45, overshoot=0.002)
+    got = hip.check_batch(q, BOTH)
+    rates = [float(((got & b) != 0).mean()) for b in (1, 2, 4)]
+    assert 0.5 < rates[0] < 0.95 and rates[1] > 0.05 and rates[2] > 0.0005, rates
+    rng = np.random.default_rng(6)
+    perm = rng.permutation(n)
+    assert (hip.check_batch(np.ascontiguousarray(q[perm]), BOTH) == got[perm]).all()
+    lo = 3 * (1 << 20) + 17
+    assert (hip.check_batch(q[lo:lo + 2_500_001], BOTH) == got[lo:lo + 2_500_001]).all()
+    idx = np.sort(rng.choice(n, 60000, replace=False))
+    assert (hip.check_batch(np.ascontiguousarray(q[idx]), BOTH | D.GH_PATH_FUSED) == got[idx]).all()
+
+
 def _scene_with_env(w, prec, **env):
     """Tuning hooks are read once, when a scene is created."""
     old = {k: os.environ.get(k) for k in env}
