@@ -301,8 +301,8 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "kernel": "k_sweep_n1 (FK + broadphase + stage 1 of the narrow phase; dominant) + k_narrow2 (exact stage) + "
-                          "k_check (hit words -> flag bytes), one launch of each per chunk of at most 2M configurations (four 2M "
-                          "chunks per 8M step), chunks rotating over 4 streams from 3M configurations per call",
+                          "k_check (hit words -> flag bytes), one launch of each per chunk of at most 4M configurations (four 2M "
+                          "chunks per 8M step on four streams, three of 2.8M on three), chunks rotating over 4 streams from 6M configurations per call",
                 "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak, "traffic": traffic,
                 "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r02/pipeline_traffic.json)",

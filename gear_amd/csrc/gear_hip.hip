@@ -101,7 +101,7 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 // Tuning and test hooks.  Read from the environment ONCE, when a scene is created; no entry point looks
 // at the environment afterwards.
 struct Knobs {
-  size_t pipe_chunk = size_t(2) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass (at most; a call's chunks are equal)
+  size_t pipe_chunk = size_t(4) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass (at most; a call's chunks are equal)
   int pipe_streams = kMaxSets;          // GEAR_HIP_PIPE_STREAMS: 1 keeps every chunk on the caller's stream
   size_t exact_cap = 0;                 // GEAR_HIP_EXACT_CAP: exact entries per sweep wavefront (tests force re-checks with it)
   bool zero_copy = true;                // GEAR_HIP_ZERO_COPY=0: host-buffer calls always copy (measuring aid)
@@ -381,7 +381,7 @@ void launch_check(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, ui
 // Every scene whose sweep fits the LDS takes the pipeline at every batch size: an RRT line of a few hundred
 // samples costs three small launches against ~100 us for the fused kernel, whose one wavefront sweeps all
 // L x O pairs and runs an exact stage of mixed pair classes.
-constexpr size_t kMultiStreamMin = size_t(3) << 20;  // batches from here on rotate their chunks over several streams
+constexpr size_t kMultiStreamMin = size_t(6) << 20;  // batches from here on rotate their chunks over several streams
 constexpr uint32_t kForceFused = 0x1000u, kForcePipe = 0x2000u;  // `what` bits for tests and profiling
 constexpr uint32_t kNoGrid = 0x4000u;                             // pipeline without the broadphase grid
 constexpr size_t kLdsCu = 160 * 1024;
@@ -460,8 +460,10 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   // Consecutive chunks are independent.  With several workspace sets they rotate over the caller's
   // stream and the aux streams (fork / join through events), so that one chunk's exact stage, which
   // cannot fill the chip, overlaps the next chunk's sweep.
-  // Forking onto the scene's streams and joining back costs ~0.1 ms per call whatever the size, so only
-  // batches of at least kMultiStreamMin configurations and two chunks rotate over several streams.
+  // Forking onto the scene's streams and joining back costs ~0.1 ms per call whatever the size, and one large chunk
+  // runs its kernels' tails once: up to 4M configurations a single chunk on the caller's stream beats four quarters
+  // on four streams by 4-8 %, from 6M on the streams win by 0-6 % (profiles/r02/chunking.txt), so only batches of
+  // at least kMultiStreamMin configurations rotate over several streams.
   // Chunks of one call are equal (a short last chunk would leave its stream idle while the others finish), and a
   // call that rotates over k streams is cut into a multiple of k chunks: 4 x 1M beats 2 x 2M, 4 x 2M beats 8 x 1M
   // (MI355X, four scenes: profiles/r02/chunking.txt).

@@ -142,12 +142,12 @@ def test_full_exact_regions_are_rechecked():
 
 
 def test_chunks_over_several_streams():
-    """From 3M configurations on a call is cut into equal chunks, a multiple of the stream count, that rotate
-    over the caller's stream and the scene's own: four chunks of 768k by default; twelve ragged ones over three
-    streams and five over one with the knobs forced.  Every cut must give the fused kernel's bytes, and so must a
+    """From 6M configurations on a call is cut into equal chunks, a multiple of the stream count, that rotate
+    over the caller's stream and the scene's own: four chunks of 1.5M by default; 21 ragged ones over three
+    streams and nine over one with the knobs forced.  Every cut must give the fused kernel's bytes, and so must a
     second call that finds the workspace sets used."""
     w = W.metric_workload()
-    n = 3 * (1 << 20) + 5
+    n = 6 * (1 << 20) + 5
     q = w.configs(n, seed=37, overshoot=0.005)
     hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
     ref = hip.check_batch(q, BOTH | D.GH_PATH_FUSED)
