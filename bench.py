@@ -191,9 +191,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
-        # the scene rotates a call's chunks over the caller's stream and up to three of its own; the box gives
-        # a process four hardware queues, and RCCL's stream needs one of them for the flag gather
-        os.environ.setdefault("GEAR_HIP_PIPE_STREAMS", "3")
+        # the scene would rotate a call's chunks over the caller's stream and three of its own; the box gives a
+        # process four hardware queues and RCCL's stream needs one for the flag gather.  One stream (two chunks of
+        # 4M one after the other) measures the same as four on this scene and more than three (4.48 / 4.47 / 4.40
+        # G configs/s at N=1, profiles/r02/chunking.txt), so the sharded run keeps the step on the caller's stream.
+        os.environ.setdefault("GEAR_HIP_PIPE_STREAMS", "1")
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -302,7 +304,7 @@ def main():
                 "bound": "valu",
                 "kernel": "k_sweep_n1 (FK + broadphase + stage 1 of the narrow phase; dominant) + k_narrow2 (exact stage) + "
                           "k_check (hit words -> flag bytes), one launch of each per chunk of at most 4M configurations (four 2M "
-                          "chunks per 8M step on four streams, three of 2.8M on three), chunks rotating over 4 streams from 6M configurations per call",
+                          "chunks per 8M step on four streams, two of 4M on one), chunks rotating over 4 streams from 6M configurations per call",
                 "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak, "traffic": traffic,
                 "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r02/pipeline_traffic.json)",
