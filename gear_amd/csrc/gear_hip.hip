@@ -86,6 +86,12 @@ struct PinBuf {
   }
 };
 constexpr size_t kZeroCopyMax = 4096;  // configurations (and edges) up to which a host-buffer call runs in place
+// Host-buffer batches above that: up to kStagedMax configurations go through the scene's page-locked staging (a
+// copy out of pageable memory costs ~0.5 ms before the first byte moves; a memcpy of a few MB is cheaper); larger
+// ones are copied straight from the caller's memory in pieces of kHostPiece, piece i + 1 on its way while piece i
+// is evaluated (tools/host_buffers.py).
+constexpr size_t kStagedMax = size_t(1) << 18;
+constexpr size_t kHostPiece = size_t(1) << 20;
 
 constexpr int kMaxSets = 4;
 
@@ -203,6 +209,7 @@ struct gh_scene {
   bool pooled = false;  // this scene is counted in its device's PipePool
   hipStream_t aux[kMaxSets] = {};  // aux[0] unused: set 0 runs on the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSets] = {};
+  hipEvent_t ev_h2d[2] = {}, ev_d2h[2] = {};  // large host-buffer calls: a piece's input is in / its flags are out (made on first use)
   int last_sets = 0;  // workspace sets the last pipeline call used
   unsigned exact_cap = 128;  // exact entries per sweep wavefront before the fused path takes the wavefront over
   bool has_mesh = false;
@@ -859,6 +866,10 @@ void gh_scene_destroy(gh_scene* sc) {
       if (sc->ev_join[k]) (void)hipEventDestroy(sc->ev_join[k]);
     }
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+    for (int k = 0; k < 2; k++) {
+      if (sc->ev_h2d[k]) (void)hipEventDestroy(sc->ev_h2d[k]);
+      if (sc->ev_d2h[k]) (void)hipEventDestroy(sc->ev_d2h[k]);
+    }
     if (sc->pooled) {  // the device's last scene takes the workspace pool with it
       PipePool& pool = g_pool[sc->device];
       std::lock_guard<std::mutex> lk(pool.mu);
@@ -947,11 +958,48 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
     std::memcpy(flags, sc->hflags.p, n);
     return GH_OK;
   }
-  if ((rc = sc->q.ensure(qb)) || (rc = sc->flags.ensure(n))) return rc;
-  GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
-  if ((rc = check_dev(sc, sc->q.p, n, what, (uint8_t*)sc->flags.p, sc->stream, false))) return rc;
-  GH_HIP(hipMemcpyAsync(flags, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
+  if ((rc = sc->q.ensure(qb)) || (rc = sc->flags.ensure(n)) || (rc = sc->hflags.ensure(n))) return rc;
+  if (n <= kStagedMax) {
+    if ((rc = sc->hq.ensure(qb))) return rc;
+    std::memcpy(sc->hq.p, q, qb);
+    GH_HIP(hipMemcpyAsync(sc->q.p, sc->hq.p, qb, hipMemcpyHostToDevice, sc->stream));
+    if ((rc = check_dev(sc, sc->q.p, n, what, (uint8_t*)sc->flags.p, sc->stream, false))) return rc;
+    GH_HIP(hipMemcpyAsync(sc->hflags.p, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
+    GH_HIP(hipStreamSynchronize(sc->stream));
+    std::memcpy(flags, sc->hflags.p, n);
+    return GH_OK;
+  }
+  for (int k = 0; k < 2; k++) {
+    if (!sc->ev_h2d[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_h2d[k], hipEventDisableTiming));
+    if (!sc->ev_d2h[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_d2h[k], hipEventDisableTiming));
+  }
+  // Inputs travel on a stream of their own (a copy out of pageable memory returns when the runtime has staged it:
+  // the device evaluates piece i meanwhile); the flags come back into page-locked memory, so that no copy into
+  // the caller's pageable array makes the stream wait, and are handed over one piece behind.
+  const size_t row = (size_t)sc->D * sc->elem();
+  hipStream_t in = sc->aux[kMaxSets - 1];
+  size_t prev_off = 0, prev_cnt = 0;
+  int i = 0;
+  for (size_t off = 0; off < n; off += kHostPiece, i++) {
+    const size_t cnt = std::min(kHostPiece, n - off);
+    GH_HIP(hipMemcpyAsync((char*)sc->q.p + off * row, (const char*)q + off * row, cnt * row, hipMemcpyHostToDevice, in));
+    GH_HIP(hipEventRecord(sc->ev_h2d[i & 1], in));
+    GH_HIP(hipStreamWaitEvent(sc->stream, sc->ev_h2d[i & 1], 0));
+    if ((rc = check_dev(sc, (char*)sc->q.p + off * row, cnt, what, (uint8_t*)sc->flags.p + off, sc->stream, false))) {
+      (void)hipStreamSynchronize(sc->stream);
+      return rc;
+    }
+    GH_HIP(hipMemcpyAsync((char*)sc->hflags.p + off, (char*)sc->flags.p + off, cnt, hipMemcpyDeviceToHost, sc->stream));
+    if (prev_cnt) {  // (its event is recorded again only two pieces on)
+      GH_HIP(hipEventSynchronize(sc->ev_d2h[(i - 1) & 1]));
+      std::memcpy(flags + prev_off, (char*)sc->hflags.p + prev_off, prev_cnt);
+    }
+    GH_HIP(hipEventRecord(sc->ev_d2h[i & 1], sc->stream));
+    prev_off = off;
+    prev_cnt = cnt;
+  }
   GH_HIP(hipStreamSynchronize(sc->stream));
+  std::memcpy(flags + prev_off, (char*)sc->hflags.p + prev_off, prev_cnt);
   return GH_OK;
 }
 

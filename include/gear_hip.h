@@ -198,7 +198,9 @@ int gh_scene_device(const gh_scene* scene);
  * flags[i]: GH_FLAG_* bits; a limit violation yields GH_FLAG_LIMIT alone
  * (the reference does not evaluate collisions then).
  *   is_feasible           == !(flags & (GH_FLAG_ENV  | GH_FLAG_LIMIT))
- *   is_feasible_with_self == !(flags & (GH_FLAG_SELF | GH_FLAG_LIMIT)) */
+ *   is_feasible_with_self == !(flags & (GH_FLAG_SELF | GH_FLAG_LIMIT))
+ * gh_check_batch takes host arrays, pageable or page-locked (large batches move about twice as fast from
+ * page-locked ones) and returns when flags[] is written; gh_check_batch_dev takes device arrays and a stream. */
 int gh_check_batch(gh_scene* scene, const void* q, size_t n, uint32_t what, uint8_t* flags);
 int gh_check_batch_dev(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
                        uint8_t* flags_dev, void* hip_stream);
