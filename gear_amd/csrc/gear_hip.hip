@@ -1145,14 +1145,36 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
   if ((rc = sc->q.ensure(std::max<size_t>(qb, 1))) || (rc = sc->flags.ensure(std::max<size_t>(n, 1))) ||
       (rc = sc->edges.ensure((n_edges + 1) * 4)) || (rc = sc->first.ensure(n_edges * 4)))
     return rc;
-  if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q, qb, hipMemcpyHostToDevice, sc->stream));
-  GH_HIP(hipMemcpyAsync(sc->edges.p, edge_off, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
+  // mid-size calls go through the scene's page-locked staging: four copies out of / into pageable memory cost more
+  // than the memcpys (kStagedMax)
+  const bool staged = n <= kStagedMax && n_edges <= kStagedMax;
+  const void* q_src = q;
+  const uint32_t* off_src = edge_off;
+  uint8_t* flags_dst = flags;
+  int32_t* first_dst = first_bad;
+  if (staged) {
+    if ((rc = sc->hq.ensure(std::max<size_t>(qb, 1))) || (rc = sc->hflags.ensure(std::max<size_t>(n, 1))) ||
+        (rc = sc->hedges.ensure((n_edges + 1) * 4)) || (rc = sc->hfirst.ensure(n_edges * 4)))
+      return rc;
+    if (qb) std::memcpy(sc->hq.p, q, qb);
+    std::memcpy(sc->hedges.p, edge_off, (n_edges + 1) * 4);
+    q_src = sc->hq.p;
+    off_src = (const uint32_t*)sc->hedges.p;
+    flags_dst = (uint8_t*)sc->hflags.p;
+    first_dst = (int32_t*)sc->hfirst.p;
+  }
+  if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q_src, qb, hipMemcpyHostToDevice, sc->stream));
+  GH_HIP(hipMemcpyAsync(sc->edges.p, off_src, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
   if ((rc = check_edges_locked(sc, sc->q.p, (const uint32_t*)sc->edges.p, n_edges, n, what, bad_mask,
                                (uint8_t*)sc->flags.p, (int32_t*)sc->first.p, sc->stream, true)))
     return rc;
-  if (n) GH_HIP(hipMemcpyAsync(flags, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
-  GH_HIP(hipMemcpyAsync(first_bad, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
+  if (n) GH_HIP(hipMemcpyAsync(flags_dst, sc->flags.p, n, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipMemcpyAsync(first_dst, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
   GH_HIP(hipStreamSynchronize(sc->stream));
+  if (staged) {
+    if (n) std::memcpy(flags, sc->hflags.p, n);
+    std::memcpy(first_bad, sc->hfirst.p, n_edges * 4);
+  }
   return GH_OK;
 }
 

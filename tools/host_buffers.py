@@ -46,3 +46,14 @@ for B in sizes:
             del q, flags
             hip.hipHostFree(pq)
             hip.hipHostFree(pf)
+
+# gh_check_edges, mid-size: segments of 16..64 samples
+for n_edges in (256, 2048, 8192):
+    qe, off = w.edges(n_edges, seed=41, dtype=np.float32, min_len=16, max_len=64)
+    for _ in range(3):
+        sc.check_edges(qe, off, D.GH_CHECK_ENV, D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        sc.check_edges(qe, off, D.GH_CHECK_ENV, D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)
+    dt = (time.perf_counter() - t0) / 10
+    print(f"gh_check_edges pageable {n_edges:6d} edges, {len(qe):7d} samples: {dt * 1e3:8.3f} ms", flush=True)
