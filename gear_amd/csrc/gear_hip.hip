@@ -759,6 +759,50 @@ int run_parts(gh_scene* sc, size_t n_parts, F&& body) {  // body(k) -> status; e
 
 }  // namespace
 
+// A large host-buffer batch, the scene's Guard held: device staging sc->q / sc->flags and page-locked sc->hflags are
+// ensured by the caller.  Inputs travel in pieces of kHostPiece on a stream of their own (a copy out of pageable memory
+// returns when the runtime has staged it: the device evaluates piece i meanwhile); the flags come back into
+// page-locked memory, so that no copy into the caller's pageable array makes the stream wait, and are handed over one
+// piece behind.  `tail` enqueues on sc->stream whatever has to follow the last piece (gh_check_edges: the first-bad
+// reduction over sc->flags); the stream is drained before the function returns.
+template <class Tail>
+static int host_pieces(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags, Tail&& tail) {
+  int rc;
+  for (int k = 0; k < 2; k++) {
+    if (!sc->ev_h2d[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_h2d[k], hipEventDisableTiming));
+    if (!sc->ev_d2h[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_d2h[k], hipEventDisableTiming));
+  }
+  const size_t row = (size_t)sc->D * sc->elem();
+  hipStream_t in = sc->aux[kMaxSets - 1];
+  size_t prev_off = 0, prev_cnt = 0;
+  int i = 0;
+  for (size_t off = 0; off < n; off += kHostPiece, i++) {
+    const size_t cnt = std::min(kHostPiece, n - off);
+    GH_HIP(hipMemcpyAsync((char*)sc->q.p + off * row, (const char*)q + off * row, cnt * row, hipMemcpyHostToDevice, in));
+    GH_HIP(hipEventRecord(sc->ev_h2d[i & 1], in));
+    GH_HIP(hipStreamWaitEvent(sc->stream, sc->ev_h2d[i & 1], 0));
+    if ((rc = check_dev(sc, (char*)sc->q.p + off * row, cnt, what, (uint8_t*)sc->flags.p + off, sc->stream, false))) {
+      (void)hipStreamSynchronize(sc->stream);
+      return rc;
+    }
+    GH_HIP(hipMemcpyAsync((char*)sc->hflags.p + off, (char*)sc->flags.p + off, cnt, hipMemcpyDeviceToHost, sc->stream));
+    if (prev_cnt) {  // (its event is recorded again only two pieces on)
+      GH_HIP(hipEventSynchronize(sc->ev_d2h[(i - 1) & 1]));
+      std::memcpy(flags + prev_off, (char*)sc->hflags.p + prev_off, prev_cnt);
+    }
+    GH_HIP(hipEventRecord(sc->ev_d2h[i & 1], sc->stream));
+    prev_off = off;
+    prev_cnt = cnt;
+  }
+  if ((rc = tail())) {
+    (void)hipStreamSynchronize(sc->stream);
+    return rc;
+  }
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  std::memcpy(flags + prev_off, (char*)sc->hflags.p + prev_off, prev_cnt);
+  return GH_OK;
+}
+
 extern "C" {
 
 const char* gh_last_error(void) { return g_last_error.c_str(); }
@@ -969,38 +1013,7 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
     std::memcpy(flags, sc->hflags.p, n);
     return GH_OK;
   }
-  for (int k = 0; k < 2; k++) {
-    if (!sc->ev_h2d[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_h2d[k], hipEventDisableTiming));
-    if (!sc->ev_d2h[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_d2h[k], hipEventDisableTiming));
-  }
-  // Inputs travel on a stream of their own (a copy out of pageable memory returns when the runtime has staged it:
-  // the device evaluates piece i meanwhile); the flags come back into page-locked memory, so that no copy into
-  // the caller's pageable array makes the stream wait, and are handed over one piece behind.
-  const size_t row = (size_t)sc->D * sc->elem();
-  hipStream_t in = sc->aux[kMaxSets - 1];
-  size_t prev_off = 0, prev_cnt = 0;
-  int i = 0;
-  for (size_t off = 0; off < n; off += kHostPiece, i++) {
-    const size_t cnt = std::min(kHostPiece, n - off);
-    GH_HIP(hipMemcpyAsync((char*)sc->q.p + off * row, (const char*)q + off * row, cnt * row, hipMemcpyHostToDevice, in));
-    GH_HIP(hipEventRecord(sc->ev_h2d[i & 1], in));
-    GH_HIP(hipStreamWaitEvent(sc->stream, sc->ev_h2d[i & 1], 0));
-    if ((rc = check_dev(sc, (char*)sc->q.p + off * row, cnt, what, (uint8_t*)sc->flags.p + off, sc->stream, false))) {
-      (void)hipStreamSynchronize(sc->stream);
-      return rc;
-    }
-    GH_HIP(hipMemcpyAsync((char*)sc->hflags.p + off, (char*)sc->flags.p + off, cnt, hipMemcpyDeviceToHost, sc->stream));
-    if (prev_cnt) {  // (its event is recorded again only two pieces on)
-      GH_HIP(hipEventSynchronize(sc->ev_d2h[(i - 1) & 1]));
-      std::memcpy(flags + prev_off, (char*)sc->hflags.p + prev_off, prev_cnt);
-    }
-    GH_HIP(hipEventRecord(sc->ev_d2h[i & 1], sc->stream));
-    prev_off = off;
-    prev_cnt = cnt;
-  }
-  GH_HIP(hipStreamSynchronize(sc->stream));
-  std::memcpy(flags + prev_off, (char*)sc->hflags.p + prev_off, prev_cnt);
-  return GH_OK;
+  return host_pieces(sc, q, n, what, flags, [] { return (int)GH_OK; });
 }
 
 int gh_check_batch_counted(gh_scene* sc, const void* q_dev, size_t n, uint32_t what, uint8_t* flags_dev,
@@ -1162,6 +1175,22 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
     off_src = (const uint32_t*)sc->hedges.p;
     flags_dst = (uint8_t*)sc->hflags.p;
     first_dst = (int32_t*)sc->hfirst.p;
+  }
+  if (!staged && n > kHostPiece && n_edges > kSmallEdgesMax) {
+    // a large batch of edges: the samples move and are evaluated piece by piece, the first-bad reduction follows
+    if ((rc = sc->hflags.ensure(n))) return rc;
+    GH_HIP(hipMemcpyAsync(sc->edges.p, edge_off, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));
+    uint32_t w = what;
+#ifndef GEAR_HIP_ABLATE
+    w &= kWhatPublic;
+#endif
+    return host_pieces(sc, q, n, w, flags, [&]() -> int {
+      hipLaunchKernelGGL(k_edge_first, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, sc->stream, (uint8_t*)sc->flags.p,
+                         (const uint32_t*)sc->edges.p, n_edges, bad_mask, (int32_t*)sc->first.p);
+      GH_HIP(hipGetLastError());
+      GH_HIP(hipMemcpyAsync(first_bad, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
+      return GH_OK;
+    });
   }
   if (qb) GH_HIP(hipMemcpyAsync(sc->q.p, q_src, qb, hipMemcpyHostToDevice, sc->stream));
   GH_HIP(hipMemcpyAsync(sc->edges.p, off_src, (n_edges + 1) * 4, hipMemcpyHostToDevice, sc->stream));

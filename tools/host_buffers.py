@@ -57,3 +57,15 @@ for n_edges in (256, 2048, 8192):
         sc.check_edges(qe, off, D.GH_CHECK_ENV, D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)
     dt = (time.perf_counter() - t0) / 10
     print(f"gh_check_edges pageable {n_edges:6d} edges, {len(qe):7d} samples: {dt * 1e3:8.3f} ms", flush=True)
+
+# configs[2]: 64k straight segments of 8..64 samples against the 256 box / cylinder field, one gh_check_edges call
+w2 = W.ur10_workload(256)
+sc2 = engine.Scene(w2.robot_keep, w2.obstacle_keep, w2.margin, 32)
+qe, off = w2.edges_lockstep(65536, seed=9, min_len=8, max_len=64)
+for _ in range(2):
+    sc2.check_edges(qe, off, D.GH_CHECK_ENV, D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)
+t0 = time.perf_counter()
+for _ in range(5):
+    sc2.check_edges(qe, off, D.GH_CHECK_ENV, D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)
+dt = (time.perf_counter() - t0) / 5
+print(f"gh_check_edges pageable  65536 edges, {len(qe):7d} samples (configs[2]): {dt * 1e3:8.3f} ms  {len(qe) / dt / 1e9:6.3f} G samples/s", flush=True)
