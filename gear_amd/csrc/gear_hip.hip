@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -63,7 +64,7 @@ struct DevBuf {
 
 }  // namespace
 
-// Host memory that the device reads and writes in place (hipHostMalloc: pinned, coherent).  The small
+// Host memory that the device reads and writes in place (hipHostMalloc: pinned, fine-grained coherent, mapped).  The small
 // synchronous calls of the host-buffer entry points (an RRT line, a start/goal check) stage their
 // arguments here and launch on it directly: no copy commands, one stream synchronisation.
 struct PinBuf {
@@ -74,7 +75,9 @@ struct PinBuf {
     if (need <= bytes) return GH_OK;
     release();
     need = std::max<size_t>(need, 4096);
-    GH_HIP(hipHostMalloc(&p, need, hipHostMallocDefault));
+    // coherent + mapped, explicitly: the host-poll completion protocol (wait_notified) needs the kernel's system-scope
+    // release store to be visible to the host in order, which a non-coherent pinned block does not promise
+    GH_HIP(hipHostMalloc(&p, need, hipHostMallocCoherent | hipHostMallocMapped));
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipHostFree(p); p = d = nullptr; return fail(GH_ERR_HIP, "hipHostGetDevicePointer failed"); }
     bytes = need;
     return GH_OK;
@@ -147,6 +150,13 @@ struct Knobs {
 namespace {
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[kMaxDevices] = {};  // device k's copy of `scratch`, as device k addresses it
+// Every scene on a device shares that device's array, and with stream == NULL each scene launches on its own
+// stream: two scenes called back to back from one host thread would overlap on the device.  The last call's end is
+// therefore recorded in an event per device (created with the address, i.e. when a scene is created: the entry point
+// itself still allocates nothing); the next call's stream waits for it before its first launch.  Calls are thereby
+// ordered in the order they were ENQUEUED; the enqueue runs under g_scratch_mu.
+hipEvent_t g_scratch_ev[kMaxDevices] = {};
+bool g_scratch_used[kMaxDevices] = {};
 
 // Address of the CURRENT device's copy of the array (looked up once per device; the caller has made
 // `device` current).
@@ -157,6 +167,7 @@ int scratch_on_device(int device, void** out) {
     void* p = nullptr;
     GH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) return fail(GH_ERR_HIP, "hipGetSymbolAddress returned no address for the workspace array");
+    GH_HIP(hipEventCreateWithFlags(&g_scratch_ev[device], hipEventDisableTiming));
     g_scratch_ptr[device] = p;
   }
   *out = g_scratch_ptr[device];
@@ -747,10 +758,23 @@ int run_parts(gh_scene* sc, size_t n_parts, F&& body) {  // body(k) -> status; e
   std::vector<int> rc(n_parts, GH_OK);
   std::vector<std::string> msg(n_parts);
   std::vector<std::thread> pool;
-  for (size_t k = 1; k < n_parts; k++)
-    pool.emplace_back([&, k] { rc[k] = body(k); if (rc[k]) msg[k] = g_last_error; });
-  rc[0] = body(0);
-  if (rc[0]) msg[0] = g_last_error;
+  auto guarded = [&](size_t k) {  // nothing may throw across the extern "C" boundary (nor out of a thread)
+    try {
+      rc[k] = body(k);
+      if (rc[k]) msg[k] = g_last_error;
+    } catch (const std::exception& e) {
+      rc[k] = GH_ERR_HIP;
+      msg[k] = std::string("exception: ") + e.what();
+    }
+  };
+  for (size_t k = 1; k < n_parts; k++) {
+    try {
+      pool.emplace_back(guarded, k);
+    } catch (const std::system_error&) {  // no thread to be had: this share runs on the calling thread
+      guarded(k);
+    }
+  }
+  guarded(0);
   for (auto& t : pool) t.join();
   for (size_t k = 0; k < n_parts; k++)
     if (rc[k]) return fail(rc[k], "device " + std::to_string(sc->parts[k]->device) + ": " + msg[k]);
@@ -955,19 +979,26 @@ int gh_check_batch_noalloc(gh_scene* sc, const void* q_dev, size_t n, uint32_t w
                 " configurations per call (" + std::to_string(n) + " given): split the batch, or use gh_check_batch_dev");
   Guard g(sc);
   if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  // held from the wait on the previous call's event to the record of this call's: calls on one device are ordered
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
   Carve region;
-  {
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    region.base = (char*)g_scratch_ptr[sc->device];  // set when the scene was created on this device
-  }
+  region.base = (char*)g_scratch_ptr[sc->device];  // set when the scene was created on this device
   if (!region.base) return fail(GH_ERR_HIP, "no workspace address for this device");
   region.bytes = kScratchBytes;
-  return check_dev(sc, q_dev, n, what, flags_dev, stream ? (hipStream_t)stream : sc->stream, false, &region);
+  hipStream_t st = stream ? (hipStream_t)stream : sc->stream;
+  if (g_scratch_used[sc->device]) GH_HIP(hipStreamWaitEvent(st, g_scratch_ev[sc->device], 0));
+  const int rc = check_dev(sc, q_dev, n, what, flags_dev, st, false, &region);
+  // (recorded after a failed enqueue too: whatever part of the call was launched still uses the array)
+  GH_HIP(hipEventRecord(g_scratch_ev[sc->device], st));
+  g_scratch_used[sc->device] = true;
+  return rc;
 }
 
 int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t* flags) {
   if (sc && !sc->parts.empty()) {
     if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
+    // a batch that one device finishes in a single ~20 us launch is not worth a host thread per device
+    if (n <= kZeroCopyMax) return gh_check_batch(sc->parts[0], q, n, what, flags);
     const size_t G = std::min<size_t>(sc->parts.size(), std::max<size_t>(n, 1));
     const size_t row = (size_t)sc->D * sc->elem();
     return run_parts(sc, G, [&](size_t k) {
@@ -1106,6 +1137,8 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
       if (edge_off[e + 1] < edge_off[e]) return fail(GH_ERR_INVALID, "edge_off must be non-decreasing");
     const size_t n = edge_off[n_edges];
     if (n && (!q || !flags)) return fail(GH_ERR_INVALID, "null argument");
+    if (n <= kZeroCopyMax && n_edges <= kZeroCopyMax)  // an RRT line or a few: one device, one launch, no threads
+      return gh_check_edges(sc->parts[0], q, edge_off, n_edges, what, bad_mask, flags, first_bad);
     // contiguous shares of whole edges, balanced by samples: share k starts at the first edge whose
     // first sample is at or beyond n * k / G
     const size_t G = std::min<size_t>(sc->parts.size(), n_edges);
@@ -1218,6 +1251,7 @@ int gh_fk_batch_dev(gh_scene* sc, const void* q_dev, size_t n, void* poses_dev, 
 int gh_fk_batch(gh_scene* sc, const void* q, size_t n, void* poses) {
   if (sc && !sc->parts.empty()) {
     if (n && (!q || !poses)) return fail(GH_ERR_INVALID, "null argument");
+    if (n <= kZeroCopyMax) return gh_fk_batch(sc->parts[0], q, n, poses);
     const size_t G = std::min<size_t>(sc->parts.size(), std::max<size_t>(n, 1));
     const size_t row = (size_t)sc->D * sc->elem(), prow = (size_t)sc->N * 7 * sc->elem();
     return run_parts(sc, G, [&](size_t k) {

@@ -332,4 +332,63 @@ const char* gp_joint_names(gp_planner* p) {
   return box->text.c_str();
 }
 
+// ---- src/funcs.rs helpers, callable without a planner (host arithmetic only: no GPU involved) ----
+namespace {
+Limits limits_from_c(const double* lo, const double* hi, const uint8_t* has, int n) {
+  Limits l((size_t)n);
+  for (int i = 0; i < n; i++) l[(size_t)i] = {has[i] != 0, Range{lo[i], hi[i]}};
+  return l;
+}
+}  // namespace
+
+int gp_generate_clamped_joint_positions_from_limits(const double* angles, int n_angles, const double* lo, const double* hi,
+                                                    const uint8_t* has_limit, int n_limits, int precision, double* out) {
+  return guarded([&]() -> int {
+    const Limits l = limits_from_c(lo, hi, has_limit, n_limits);
+    if (precision == 32) {
+      auto r = generate_clamped_joint_positions_from_limits<float>(to_vec<float>(angles, n_angles), l);
+      for (size_t i = 0; i < r.size(); i++) out[i] = (double)r[i];
+    } else {
+      auto r = generate_clamped_joint_positions_from_limits<double>(to_vec<double>(angles, n_angles), l);
+      for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+    }
+    return GP_OK;
+  });
+}
+
+int gp_generate_random_joint_positions_from_limits(const double* lo, const double* hi, const uint8_t* has_limit, int n_limits,
+                                                   int precision, uint64_t seed, size_t k, double* out) {
+  return guarded([&]() -> int {
+    const Limits l = limits_from_c(lo, hi, has_limit, n_limits);
+    Rng rng(seed);
+    for (size_t r = 0; r < k; r++) {
+      if (precision == 32) {
+        auto v = generate_random_joint_positions_from_limits<float>(l, rng);
+        for (size_t i = 0; i < v.size(); i++) out[r * (size_t)n_limits + i] = (double)v[i];
+      } else {
+        auto v = generate_random_joint_positions_from_limits<double>(l, rng);
+        for (size_t i = 0; i < v.size(); i++) out[r * (size_t)n_limits + i] = v[i];
+      }
+    }
+    return GP_OK;
+  });
+}
+
+int gp_modify_to_nearest_angle(const double* vec1, double* vec2, int n, const double* lo, const double* hi,
+                               const uint8_t* has_limit, int precision) {
+  return guarded([&]() -> int {
+    const Limits l = limits_from_c(lo, hi, has_limit, n);
+    if (precision == 32) {
+      auto b = to_vec<float>(vec2, n);
+      modify_to_nearest_angle<float>(to_vec<float>(vec1, n), b, l);
+      for (int i = 0; i < n; i++) vec2[i] = (double)b[(size_t)i];
+    } else {
+      auto b = to_vec<double>(vec2, n);
+      modify_to_nearest_angle<double>(to_vec<double>(vec1, n), b, l);
+      for (int i = 0; i < n; i++) vec2[i] = b[(size_t)i];
+    }
+    return GP_OK;
+  });
+}
+
 }  // extern "C"

@@ -22,6 +22,8 @@ SYMBOLS = [
     "gp_has_any_colliding_with_self", "gp_colliding_link_names", "gp_colliding_link_names_with_self",
     "gp_is_feasible_batch", "gp_plan", "gp_plan_avoid_self_collision", "gp_last_collision_names",
     "gp_feasible_ik_seeds", "gp_joint_positions", "gp_joint_names",
+    "gp_generate_clamped_joint_positions_from_limits", "gp_generate_random_joint_positions_from_limits",
+    "gp_modify_to_nearest_angle",
 ]
 
 GP_ERR = {-10: "CollisionStart", -11: "CollisionEnd", -12: "SelfCollisionStart", -13: "SelfCollisionEnd",
@@ -71,6 +73,9 @@ def lib():
         L.gp_joint_positions.argtypes = [vp, i32p, C.c_int, dp]
         L.gp_joint_names.argtypes = [vp]
         L.gp_joint_names.restype = cp
+        L.gp_generate_clamped_joint_positions_from_limits.argtypes = [dp, C.c_int, dp, dp, u8p, C.c_int, C.c_int, dp]
+        L.gp_generate_random_joint_positions_from_limits.argtypes = [dp, dp, u8p, C.c_int, C.c_int, C.c_uint64, C.c_size_t, dp]
+        L.gp_modify_to_nearest_angle.argtypes = [dp, dp, C.c_int, dp, dp, u8p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -83,6 +88,51 @@ def _i32(v):
 def _f64(v):
     a = np.ascontiguousarray(v, np.float64)
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _limits(limits):
+    """limits: sequence of None | (lo, hi), the reference's Vec<Option<Range>>."""
+    lo = np.array([0.0 if l is None else l[0] for l in limits], np.float64)
+    hi = np.array([0.0 if l is None else l[1] for l in limits], np.float64)
+    has = np.array([l is not None for l in limits], np.uint8)
+    return lo, hi, has
+
+
+def _raise(rc):
+    if rc < 0:
+        raise GearHostError(rc, lib().gp_last_error().decode())
+
+
+def generate_clamped_joint_positions_from_limits(angles, limits, precision: int = 64) -> np.ndarray:
+    """gear::generate_clamped_joint_positions_from_limits of the C++ host layer (funcs.rs:25-54)."""
+    a, ap = _f64(angles)
+    lo, hi, has = _limits(limits)
+    out = np.zeros(len(limits), np.float64)
+    _raise(lib().gp_generate_clamped_joint_positions_from_limits(
+        ap, len(a), lo.ctypes.data_as(C.POINTER(C.c_double)), hi.ctypes.data_as(C.POINTER(C.c_double)),
+        has.ctypes.data_as(C.POINTER(C.c_uint8)), len(limits), precision, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def generate_random_joint_positions_from_limits(limits, k: int, seed: int = 0, precision: int = 64) -> np.ndarray:
+    """k draws of gear::generate_random_joint_positions_from_limits (funcs.rs:76-87), [k][len(limits)]."""
+    lo, hi, has = _limits(limits)
+    out = np.zeros((k, len(limits)), np.float64)
+    _raise(lib().gp_generate_random_joint_positions_from_limits(
+        lo.ctypes.data_as(C.POINTER(C.c_double)), hi.ctypes.data_as(C.POINTER(C.c_double)),
+        has.ctypes.data_as(C.POINTER(C.c_uint8)), len(limits), precision, seed, k, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def modify_to_nearest_angle(vec1, vec2, limits, precision: int = 64) -> np.ndarray:
+    """gear::modify_to_nearest_angle (funcs.rs:98-119); returns the modified copy of vec2."""
+    a, ap = _f64(vec1)
+    b = np.array(vec2, np.float64)
+    lo, hi, has = _limits(limits)
+    _raise(lib().gp_modify_to_nearest_angle(ap, b.ctypes.data_as(C.POINTER(C.c_double)), len(b),
+                                            lo.ctypes.data_as(C.POINTER(C.c_double)), hi.ctypes.data_as(C.POINTER(C.c_double)),
+                                            has.ctypes.data_as(C.POINTER(C.c_uint8)), precision))
+    return b
 
 
 class HostCompound:

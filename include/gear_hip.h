@@ -19,10 +19,14 @@
  *    optional hipStream_t (as void*), the others take host pointers and are
  *    synchronous;
  *  - a gh_scene is immutable after creation and may be shared by host threads
- *    (calls on one scene serialise on the scene's stream).  A scene owns one
- *    device workspace: asynchronous `_dev` calls on the SAME scene must all be
- *    enqueued on the same stream (or be ordered by the caller); use one scene
- *    per stream for concurrent launches;
+ *    (every entry point holds the scene's lock while it enqueues; host-buffer
+ *    calls hold it until their results are back).  The large-batch kernels'
+ *    workspace belongs to the DEVICE, not to a scene: a pool of up to four sets
+ *    shared by every scene on that device, each set ordered by an event of its
+ *    last use, so asynchronous `_dev` calls may be enqueued on any streams, from
+ *    any scenes, in any order — a call that needs a set still in use makes its
+ *    stream wait for it.  A scene's own staging buffers serve one call at a
+ *    time (the lock);
  *  - scalars in descriptors are f64; `precision` (32|64) selects the arithmetic
  *    type T of the whole path, converting exactly where the reference converts
  *    (na::convert of URDF f64 values, src/collision/urdf.rs:18-27).

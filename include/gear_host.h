@@ -107,6 +107,21 @@ int gp_feasible_ik_seeds(gp_planner* p, const int32_t* using_joints, int n_using
 int gp_joint_positions(gp_planner* p, const int32_t* using_joints, int n_using, double* q);
 const char* gp_joint_names(gp_planner* p);
 
+/* src/funcs.rs helpers, pure host arithmetic (no planner, no GPU).  Limits cross as three arrays:
+ * has_limit[i] != 0 <=> Some(Range::new(lo[i], hi[i])), else None.  precision 32|64 = the type parameter T
+ * the arithmetic runs in; values cross as double.
+ * generate_clamped_joint_positions_from_limits (funcs.rs:25-54; test funcs.rs:203-211): out[n_limits];
+ *   n_angles != n_limits -> GP_ERR_DOF_MISMATCH, as the reference's Err(DofMismatch).
+ * generate_random_joint_positions_from_limits (funcs.rs:76-87; test funcs.rs:196-202): k draws, out[k][n_limits],
+ *   from the seedable stand-in for rand::random.
+ * modify_to_nearest_angle (funcs.rs:98-119; doctest funcs.rs:91-97): vec2 is modified in place. */
+int gp_generate_clamped_joint_positions_from_limits(const double* angles, int n_angles, const double* lo, const double* hi,
+                                                    const uint8_t* has_limit, int n_limits, int precision, double* out);
+int gp_generate_random_joint_positions_from_limits(const double* lo, const double* hi, const uint8_t* has_limit, int n_limits,
+                                                   int precision, uint64_t seed, size_t k, double* out);
+int gp_modify_to_nearest_angle(const double* vec1, double* vec2, int n, const double* lo, const double* hi,
+                               const uint8_t* has_limit, int precision);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,7 @@ def lib():
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_explain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_int]
         L.orc_check_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8,
                                       C.c_void_p, C.c_void_p]
         L.orc_fk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -103,6 +104,23 @@ class OracleScene:
         if want_stats:
             out.append(stats)
         return out[0] if len(out) == 1 else tuple(out)
+
+    KINDS = ("box", "ball", "triangle", "mesh")
+    GJK_EXITS = ("none", "zero_projection", "no_progress", "converged", "point_rejected", "tetra_closest",
+                 "tetra_intersection", "iteration_cap")
+
+    def explain(self, q_row, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF, window=0.0, cap=256):
+        """Every pair of ONE configuration that is within `window` of the margin or reported free without
+        its lower bound certifying it: list of dicts (self, id_a, id_b, kinds, d, lower, iters, exit)."""
+        q = self._q(np.asarray(q_row).reshape(1, -1))
+        out = np.zeros((cap, 9), np.float64)
+        n = lib().orc_explain(self.h, _ptr(q), what, float(window), _ptr(out), cap)
+        recs = []
+        for r in out[:min(n, cap)]:
+            recs.append({"self": bool(r[0]), "id_a": int(r[1]), "id_b": int(r[2]),
+                         "kinds": self.KINDS[int(r[3])] + "-" + self.KINDS[int(r[4])], "d": float(r[5]),
+                         "lower": float(r[6]), "iters": int(r[7]), "exit": self.GJK_EXITS[int(r[8])]})
+        return recs
 
     def check_edges(self, q, edge_off, what=D.GH_CHECK_ENV, bad_mask=D.GH_FLAG_ENV | D.GH_FLAG_LIMIT):
         q = self._q(q)

@@ -424,6 +424,20 @@ struct VoronoiSimplex {
 };
 
 enum GjkKind { GJK_INTERSECTION, GJK_CLOSEST, GJK_NO_INTERSECTION };
+// Oracle-side diagnostic (not part of ncollide's result): how the last GJK run on this thread ended.
+// tests/parity.py records it for every mismatch it excuses, so that nobody has to infer why the run stopped.
+enum GjkExit {
+  GX_NONE = 0,
+  GX_ZERO_PROJECTION = 1,  // |proj| <= eps_tol: Intersection
+  GX_NO_PROGRESS = 2,      // max_bound >= old_max_bound: ClosestPoints from the previous simplex
+  GX_CONVERGED = 3,        // max_bound - min_bound <= eps_rel * max_bound
+  GX_POINT_REJECTED = 4,   // VoronoiSimplex::add_point refused the new support point (ABSOLUTE thresholds eps_tol)
+  GX_TETRA_CLOSEST = 5,    // simplex grew to a tetrahedron with min_bound >= eps_tol
+  GX_TETRA_INTERSECTION = 6,
+  GX_ITERATION_CAP = 7
+};
+struct GjkDetail { int iters = 0; int exit = GX_NONE; };
+inline GjkDetail& last_gjk() { static thread_local GjkDetail d; return d; }
 template <class T>
 struct GjkResult {
   GjkKind kind;
@@ -459,7 +473,7 @@ inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, con
   GjkResult<T> res{GJK_INTERSECTION, {0, 0, 0}, {0, 0, 0}, 0, T(0)};
   V3<T> proj = simplex.project_origin_and_reduce();
   T n2 = norm2(proj);
-  if (!(n2 > T(0))) return res;
+  if (!(n2 > T(0))) { last_gjk() = {0, GX_ZERO_PROJECTION}; return res; }
   V3<T> old_dir = -(proj / std::sqrt(n2));
   T max_bound = std::numeric_limits<T>::max();
   V3<T> dir{};
@@ -474,12 +488,14 @@ inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, con
     } else {
       res.kind = GJK_INTERSECTION;
       res.iters = niter;
+      last_gjk() = {niter, GX_ZERO_PROJECTION};
       return res;
     }
     if (max_bound >= old_max_bound) {
       res.kind = GJK_CLOSEST;
       gjk_witness(simplex, true, res.p1, res.p2);
       res.iters = niter;
+      last_gjk() = {niter, GX_NO_PROGRESS};
       return res;
     }
     CSOPoint<T> cso = cso_from_shapes(m1, g1, m2, g2, dir);
@@ -489,12 +505,14 @@ inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, con
       res.kind = GJK_CLOSEST;
       gjk_witness(simplex, false, res.p1, res.p2);
       res.iters = niter;
+      last_gjk() = {niter, GX_CONVERGED};
       return res;
     }
     if (!simplex.add_point(cso)) {
       res.kind = GJK_CLOSEST;
       gjk_witness(simplex, false, res.p1, res.p2);
       res.iters = niter;
+      last_gjk() = {niter, GX_POINT_REJECTED};
       return res;
     }
     old_dir = dir;
@@ -507,12 +525,18 @@ inline GjkResult<T> gjk_closest_points(const Iso<T>& m1, const Shape<T>& g1, con
         res.kind = GJK_INTERSECTION;
       }
       res.iters = niter;
+      last_gjk() = {niter, res.kind == GJK_CLOSEST ? GX_TETRA_CLOSEST : GX_TETRA_INTERSECTION};
       return res;
     }
     niter += 1;
+    // Iteration cap.  SURVEY a6 recalls "100 iterations" for ncollide 0.23's distance query; what is recalled of
+    // gjk::closest_points itself is a loop that gives up after a large fixed count (10 000 here).  Either figure is
+    // [recalled] and unpinned by the reference; neither is ever reached on convex polytopes with the exits above
+    // (the largest count seen in the parity runs is < 40), so the choice cannot change a flag.
     if (niter == 10000) {
       res.kind = GJK_NO_INTERSECTION;
       res.iters = niter;
+      last_gjk() = {niter, GX_ITERATION_CAP};
       return res;
     }
   }
@@ -663,6 +687,7 @@ inline T distance_composite(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& 
   };
   Shape<T> tri;
   tri.kind = K_TRI;
+  GjkDetail best_detail;
   push(aabb_msum_dist(g1.bvh[0].bb, shift, marg), 0);
   while (hn > 0) {
     Ent e = pop();
@@ -676,7 +701,7 @@ inline T distance_composite(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& 
       // map_part_at hands (m1, triangle); argument order follows the caller's
       T lo = 0;
       T d = swapped ? distance(m2, g2, m1, tri, st, &lo) : distance(m1, tri, m2, g2, st, &lo);
-      if (d < best) best = d;
+      if (d < best) { best = d; best_detail = last_gjk(); }
       if (lo < best_lower) best_lower = lo;
     } else {
       T ll = aabb_msum_dist(g1.bvh[nd.left].bb, shift, marg);
@@ -687,6 +712,7 @@ inline T distance_composite(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& 
   }
   // pruned triangles have an AABB bound >= the best distance at the time, hence >= best_lower
   if (lower) *lower = std::min(best_lower, best);
+  last_gjk() = best_detail;  // the run that produced the minimum
   return best;
 }
 
@@ -699,6 +725,7 @@ T distance(const Iso<T>& m1, const Shape<T>& g1, const Iso<T>& m2, const Shape<T
     T sum = g1.radius + g2.radius;
     T d = d2 <= sum * sum ? T(0) : std::sqrt(d2) - sum;
     if (lower) *lower = d;
+    last_gjk() = {0, GX_NONE};
     return d;
   }
   if (g1.kind != K_MESH && g2.kind != K_MESH) return distance_support_maps(m1, g1, m2, g2, st, lower);
@@ -966,6 +993,44 @@ struct Scene {
       }
       if (hit && !yield((int)p)) return;
     }
+  }
+
+  // Oracle-side diagnostic: every pair of one configuration whose decision is close (|d - margin| <= window) or
+  // uncertified (reported free although the run's certified lower bound is below the margin), with what the
+  // distance query returned and how its GJK run ended.  emit(is_self, id_a, id_b, kind_a, kind_b, d, lower, iters, exit):
+  // env pairs: id_a = node * 64 + shape-within-node, id_b = obstacle; self pairs: id_a = pair, id_b = shape1 * 64 + shape2.
+  template <class F>
+  void explain_config(const T* q, uint32_t what, T window, F&& emit) const {
+    std::vector<T> pos;
+    initial_positions(pos);
+    std::vector<Iso<T>> world;
+    if (what & GH_CHECK_NO_LIMITS) set_joint_positions_unchecked(q, pos);
+    else if (!set_joint_positions(q, pos)) return;
+    update_transforms(pos, world);
+    auto note = [&](int self, int ida, int idb, const Shape<T>& a, const Shape<T>& b, T d, T lo) {
+      if (std::abs(d - margin) <= window || (!(d < margin) && lo < margin))
+        emit(self, ida, idb, a.kind, b.kind, d, lo, last_gjk().iters, last_gjk().exit);
+    };
+    if (what & GH_CHECK_ENV)
+      for (size_t o = 0; o < obstacles.size(); o++)
+        for (size_t ni = 0; ni < nodes.size(); ni++)
+          for (size_t k = 0; k < link_shapes[ni].size(); k++) {
+            const LinkShape<T>& ls = link_shapes[ni][k];
+            T lo = 0;
+            T d = distance(imul(world[ni], ls.local), ls.shape, obstacles[o].pose, obstacles[o].shape, (Stats*)nullptr, &lo);
+            note(0, (int)(ni * 64 + k), (int)o, ls.shape, obstacles[o].shape, d, lo);
+          }
+    if (what & GH_CHECK_SELF)
+      for (size_t p = 0; p < pairs.size(); p++) {
+        int n1 = pairs[p][0], n2 = pairs[p][1];
+        for (size_t i1 = 0; i1 < link_shapes[n1].size(); i1++)
+          for (size_t i2 = 0; i2 < link_shapes[n2].size(); i2++) {
+            const LinkShape<T>&o1 = link_shapes[n1][i1], &o2 = link_shapes[n2][i2];
+            T lo = 0;
+            T d = distance(imul(world[n1], o1.local), o1.shape, imul(world[n2], o2.local), o2.shape, (Stats*)nullptr, &lo);
+            note(1, (int)p, (int)(i1 * 64 + i2), o1.shape, o2.shape, d, lo);
+          }
+      }
   }
 
   // flags for one configuration.  faithful = early exits exactly as the

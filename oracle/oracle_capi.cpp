@@ -141,6 +141,25 @@ int orc_check(void* h, const void* q, size_t n, uint32_t what, int faithful, int
   return 0;
 }
 
+// Diagnostic for tests/parity.py: the close or uncertified pairs of ONE configuration (Scene::explain_config).
+// out: records of 9 doubles {is_self, id_a, id_b, kind_a, kind_b, d, lower, gjk iterations, GjkExit}; returns
+// the number of records found (at most `cap` are written).
+int orc_explain(void* h, const void* q_row, uint32_t what, double window, double* out, int cap) {
+  OrcScene* s = (OrcScene*)h;
+  if (!s) return -1;
+  int n = 0;
+  auto emit = [&](int self, int ida, int idb, int ka, int kb, double d, double lo, int iters, int exit) {
+    if (n < cap) {
+      double* r = out + 9 * (size_t)n;
+      r[0] = self; r[1] = ida; r[2] = idb; r[3] = ka; r[4] = kb; r[5] = d; r[6] = lo; r[7] = iters; r[8] = exit;
+    }
+    n++;
+  };
+  if (s->precision == 32) s->s32->explain_config((const float*)q_row, what, (float)window, emit);
+  else s->s64->explain_config((const double*)q_row, what, window, emit);
+  return n;
+}
+
 // first infeasible sample per edge, sequentially, stopping at the first failure
 // exactly like rrt's stepping with the is_feasible closure
 // (joint_path_planner.rs:168-188).  flags of samples after the first failure of

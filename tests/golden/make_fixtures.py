@@ -10,6 +10,8 @@ Outputs:
     sample_robot.json, obstacles.json   the numeric content, in gear_amd.urdf's dict form
     collision_check.json                the three known-answer cases of
                                         src/planner/joint_path_planner.rs:373-419 (f32, margin 0.01)
+    funcs.json                          the vectors of src/funcs.rs's doctest (:91-97) and of
+                                        test_funcs (:189-212): inputs and expected outputs
 """
 import json
 import os
@@ -45,6 +47,22 @@ def main():
     }
     with open(os.path.join(HERE, "collision_check.json"), "w") as fh:
         json.dump(golden, fh, indent=1)
+    # src/funcs.rs — transcribed test vectors.  A limit is null (None) or [min, max] (k::joint::Range::new).
+    funcs = {
+        "source": "src/funcs.rs:91-97 (doctest of modify_to_nearest_angle), src/funcs.rs:189-212 (test_funcs)",
+        "modify_to_nearest_angle": {
+            "vec1": [1.0, 0.5], "vec2": [0.1, 10.0], "limits": [[0.0, 0.2], None],
+            "expect_exact": {"0": 0.1}, "expect_close": {"1": 3.716814}, "tolerance": 0.000001},
+        "generate_clamped_joint_positions_from_limits": {
+            "limits": [None, [-1.0, 1.0], [0.0, 0.1]],
+            "dof_mismatch_input": [0.1],
+            "input": [100.0, -2.0, 0.5], "expect": [100.0, -1.0, 0.1], "tolerance": 0.00001},
+        "generate_random_joint_positions_from_limits": {
+            "limits": [None, [-1.0, 1.0], [0.0, 0.1]], "draws": 1000,
+            "ranges_half_open": [["-PI", "PI"], [-1.0, 1.0], [0.0, 0.1]]},
+    }
+    with open(os.path.join(HERE, "funcs.json"), "w") as fh:
+        json.dump(funcs, fh, indent=1)
 
 
 if __name__ == "__main__":

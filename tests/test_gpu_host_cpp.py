@@ -225,3 +225,45 @@ def test_plan_in_a_cluttered_field(tmp_path):
     safe = certain(band, 32)
     assert safe.mean() > 0.8
     assert ((flags[safe] & (D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)) == 0).all()
+
+
+def test_ik_seeds_on_a_robot_with_continuous_joints(tmp_path):
+    """RandomInitializeIKSolver's seed draw (src/ik.rs:77-79) on joints WITHOUT limits: the [-pi, pi) draw of
+    funcs.rs:84 and the wrap of modify_to_nearest_angle (funcs.rs:104-116) run in the C++ host layer, and the
+    batch's feasibility bits equal the oracle's on the same seeds."""
+    import dataclasses
+    robot = W.arm7_robot()
+    for k in (0, 4, 6):      # j0, j4, j6 become `continuous`: no Range (k::urdf), so no limit gate either
+        robot.joints[k] = dataclasses.replace(robot.joints[k], type="continuous", lower=0.0, upper=0.0)
+    p = tmp_path / "arm7c.urdf"
+    p.write_text(urdf.robot_to_xml(robot))
+    field = W.obstacle_field(64, 21, ("box", "ball"), (0.6, 0.4))
+    obs = H.HostCompound.from_specs(field.shapes)
+    for prec, dtype in ((32, np.float32), (64, np.float64)):
+        pl = H.HostPlanner(str(p), 0.01, prec, seed=5)
+        u = pl.using_joints()
+        d = pl.describe()
+        free_cols = [c for c, i in enumerate(u) if not d["nodes"][i]["has_limit"]]
+        assert free_cols == [0, 4, 6]
+        initial = np.array([3.0, 0.1, 0.2, -0.3, -3.0, 0.4, 2.5])
+        seeds, ok = pl.feasible_ik_seeds(u, initial, 4096, obs)
+        ini = initial.astype(dtype).astype(np.float64)
+        tol = 1e-5 if prec == 32 else 1e-12
+        for c in free_cols:      # nearest representative of the drawn angle: within pi of the initial value
+            assert (np.abs(seeds[:, c] - ini[c]) <= np.pi + tol).all()
+            assert (np.abs(seeds[:, c]) > np.pi).any()           # the +-2 pi branches ran
+            assert np.ptp(seeds[:, c]) > 6.0                     # the whole circle was drawn from
+        chain = urdf.Chain.from_urdf(robot)
+        lo, hi = W.joint_limits(chain, u)
+        for c in range(len(u)):
+            if c not in free_cols:
+                assert (seeds[:, c] >= lo[c]).all() and (seeds[:, c] <= hi[c]).all()
+        assert (ok == pl.is_feasible_batch(u, seeds, obs)).all()
+        assert ok.any() and not ok.all()
+        w = W.Workload("arm7_continuous", robot, field, 0.01)
+        ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, 0.01, prec)
+        flags, band = ora.check(seeds.astype(dtype), D.GH_CHECK_ENV, threads=8)
+        safe = certain(band, prec)
+        assert safe.mean() > 0.95
+        assert (flags & D.GH_FLAG_LIMIT).sum() == 0              # unlimited joints beyond +-pi raise no limit flag
+        assert (ok[safe] == ((flags[safe] & (D.GH_FLAG_ENV | D.GH_FLAG_LIMIT)) == 0)).all()

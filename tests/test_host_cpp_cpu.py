@@ -91,3 +91,53 @@ def test_xml_reader_handles_comments_and_quotes(tmp_path):
     assert [n["name"] for n in d["nodes"]] == ["root", "j1", "j3", "j2"]     # children popped in reverse order
     assert d["nodes"][0]["shapes"][0]["kind"] == D.GH_SHAPE_BALL
     assert d["nodes"][1]["has_limit"] == 0 and d["nodes"][3]["has_limit"] == 1
+
+
+# ---- src/funcs.rs helpers of the C++ host layer against the reference's own vectors (tests/golden/funcs.json) ----
+def _limits_of(v):
+    return [None if l is None else tuple(l) for l in v]
+
+
+@pytest.fixture(scope="module")
+def funcs_golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "funcs.json")) as fh:
+        return json.load(fh)
+
+
+def test_modify_to_nearest_angle_doctest(funcs_golden):
+    g = funcs_golden["modify_to_nearest_angle"]              # funcs.rs:91-97
+    a = H.modify_to_nearest_angle(g["vec1"], g["vec2"], _limits_of(g["limits"]), 64)
+    for k, v in g["expect_exact"].items():
+        assert a[int(k)] == v, "no change"
+    for k, v in g["expect_close"].items():
+        assert abs(a[int(k)] - v) < g["tolerance"]
+    # the two other branches (funcs.rs:107-116): +2 pi, and already nearest
+    lim = [None]
+    assert abs(H.modify_to_nearest_angle([3.0], [-3.0], lim)[0] - (-3.0 + 2 * np.pi)) < 1e-12
+    assert H.modify_to_nearest_angle([0.2], [0.3], lim)[0] == 0.3
+    # f32 arithmetic (N = f32): same doctest inside the f32 rounding of the result
+    a32 = H.modify_to_nearest_angle(g["vec1"], g["vec2"], _limits_of(g["limits"]), 32)
+    assert a32[0] == float(np.float32(0.1)) and abs(a32[1] - 3.716814) < 1e-5
+
+
+def test_generate_clamped_joint_positions_from_limits(funcs_golden):
+    g = funcs_golden["generate_clamped_joint_positions_from_limits"]   # funcs.rs:203-211
+    lim = _limits_of(g["limits"])
+    with pytest.raises(H.GearHostError) as e:
+        H.generate_clamped_joint_positions_from_limits(g["dof_mismatch_input"], lim)
+    assert e.value.kind == "DofMismatch"
+    got = H.generate_clamped_joint_positions_from_limits(g["input"], lim)
+    assert np.all(np.abs(got - np.array(g["expect"])) < g["tolerance"])
+    np.testing.assert_array_equal(got, g["expect"])          # clamping returns the limit itself
+
+
+def test_generate_random_joint_positions_from_limits(funcs_golden):
+    g = funcs_golden["generate_random_joint_positions_from_limits"]    # funcs.rs:196-202
+    for precision in (64, 32):
+        a = H.generate_random_joint_positions_from_limits(_limits_of(g["limits"]), g["draws"], seed=7, precision=precision)
+        assert a.shape == (g["draws"], len(g["limits"]))
+        assert np.all(a[:, 0] >= -np.pi) and np.all(a[:, 0] < np.pi)       # None: [-PI, PI)
+        assert np.all(a[:, 1] >= -1.0) and np.all(a[:, 1] < 1.0)
+        assert np.all(a[:, 2] >= 0.0) and np.all(a[:, 2] < 0.1 + (1e-8 if precision == 32 else 0.0))
+        assert a[:, 0].min() < -2.5 and a[:, 0].max() > 2.5                # the whole circle is drawn from
