@@ -31,7 +31,18 @@ from gear_amd import workloads as W
 
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "pipeline_traffic.json")   # tools/pmc_traffic.py
+# committed rocprofv3 PMC summaries (bench.py itself cannot run under the profiler): fabric traffic per configuration
+# (tools/pmc_traffic.py) and the issue-side counters of the dominant kernel (tools/attrib_sweep.sh); newest round first
+def _first_existing(*names):
+    for n in names:
+        if os.path.exists(n):
+            return n
+    return names[-1]
+
+
+TRAFFIC_JSON = _first_existing(os.path.join(ROOT, "profiles", "r03", "pipeline_traffic.json"),
+                               os.path.join(ROOT, "profiles", "r02", "pipeline_traffic.json"))
+ISSUE_JSON = os.path.join(ROOT, "profiles", "r03", "attrib_k_sweep_n1.json")
 WHAT = D.GH_CHECK_ENV | D.GH_CHECK_SELF
 
 
@@ -43,6 +54,17 @@ def measured_traffic(batch):
         with open(TRAFFIC_JSON) as f:
             t = json.load(f)
         return float(t["total_bytes_per_config"]) * batch
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def measured_issue():
+    """VALU issue occupancy of the dominant kernel from the committed SQ-counter passes (a constant read from a
+    file, like `traffic`: not measured in this run)."""
+    try:
+        with open(ISSUE_JSON) as f:
+            t = json.load(f)
+        return {k: t["issue"][k] for k in ("valu_issue_frac", "valu_insts_per_wave", "wave_cycles", "source")}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -94,18 +116,27 @@ def cpu_baseline(w, precision, q_gpu=None, flags_gpu=None, seconds=12.0):
     """The reference's CPU path as restated by oracle/ ("port"): is_feasible-style early exits and the
     per-obstacle FK the reference does, (i) single-threaded (the reference is !Send) and (ii) one
     independent chain per thread on all host cores available to this process.  This leg is the only
-    place bench.py touches oracle/; while it is here it also checks the GPU's flags of the first timed
-    configurations (q_gpu, flags_gpu: host copies) against it."""
+    place bench.py touches oracle/; while it is here it also checks the GPU's flags of configurations spread
+    over the last timed step (q_gpu, flags_gpu: host copies) against it, in the three figures of tests/parity.py:
+    in_band / oracle_uncertified (each adjudicated by the f64 oracle, evidence attached) / outside."""
     from oracle import binding as orc
     ora = orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, precision)
     dtype = np.float32 if precision == 32 else np.float64
     cores, affinity, quota = host_threads()
     parity = None
     if q_gpu is not None:
-        from tests.parity import compare_flags
+        from tests.parity import adjudicate, compare_flags
         want, band = ora.check(q_gpu, WHAT, threads=cores)
         rep = compare_flags(flags_gpu, want, band, precision)
-        parity = {kk: rep[kk] for kk in ("total", "mismatched", "in_band", "oracle_uncertified", "outside")}
+        if precision == 32:
+            adjudicate(rep, flags_gpu, want, q_gpu, WHAT, orc.OracleScene(w.robot_keep, w.obstacle_keep, w.margin, 64), ora32=ora)
+        else:
+            rep["adjudicated"], rep["unresolved"] = 0, rep["oracle_uncertified"]
+            rep["outside"] += rep["oracle_uncertified"]      # the f64 oracle certifies its own answers: nothing is excused
+        parity = {kk: rep[kk] for kk in ("total", "mismatched", "in_band", "oracle_uncertified", "adjudicated", "unresolved", "outside")}
+        parity["max_margin_minus_d64"] = rep.get("max_margin_minus_d64")
+        parity["cases"] = rep.get("cases", [])[:8]
+        parity["sample"] = "configurations evenly spread over the batch of the last timed step"
     probe = w.configs(32, seed=999, dtype=dtype)
     t0 = time.perf_counter()
     ora.check(probe, faithful=True, redundant_fk=True, threads=1, want_band=False)
@@ -161,7 +192,7 @@ def side_measurement(w, precision, B, device, stream, steps, warmup, seed):
     rates = [float((flags & b).ne(0).float().mean()) for b in (1, 2, 4)]
     return {"workload": w.name, "dtype": "f32" if precision == 32 else "f64", "value": B * steps / wall, "unit": "configs/s",
             "batch": B, "ms_per_step": wall / steps * 1e3, "kernel_ms": kms,
-            "roofline_frac": fpc * B / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[precision],
+            "algorithmic_frac": fpc * B / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[precision],
             "algorithmic_flops_per_config": fpc, "sat_per_config": mix["sat_per_config"], "exact_per_config": mix["exact_per_config"],
             "flag_rates": {"env": rates[0], "self": rates[1], "limit": rates[2]}}
 
@@ -178,6 +209,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f64 and free-space sub-records")
+    ap.add_argument("--parity-sample", type=int, default=4096, help="configurations of the last timed step checked against the oracle")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="take the N > 1 code path (RCCL process group, asynchronous all-gather of the flag bytes, double flag "
+                         "buffers, the step on the caller's stream, counter all-reduce) whatever the world size: lets a 1-GPU box "
+                         "run every line the 8-GPU run runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,8 +224,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_collectives     # the N > 1 code path
+    if sharded:
         import torch.distributed as dist
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)               # plain `python bench.py --force-collectives`: a one-rank group
         dist.init_process_group("nccl", device_id=device)
         # the scene would rotate a call's chunks over the caller's stream and three of its own; the box gives a
         # process four hardware queues and RCCL's stream needs one for the flag gather.  One stream (two chunks of
@@ -206,7 +245,7 @@ def main():
     q = device_configs(w, B, seed=1234 + rank, dtype=dtype, device=device)   # this rank's shard
     qs = [q] + [device_configs(w, B, seed=1234 + rank + 7919 * j, dtype=dtype, device=device) for j in range(1, N_INPUTS)]
     flags = torch.zeros(B, dtype=torch.uint8, device=device)
-    gathered = torch.zeros(B * world, dtype=torch.uint8, device=device) if world > 1 else None
+    gathered = torch.zeros(B * world, dtype=torch.uint8, device=device) if sharded else None
     # a non-default torch stream: its handle is what the C ABI launches on, so torch.cuda.Event
     # (HIP events on that same stream) brackets the kernels themselves
     tstream = torch.cuda.Stream(device=device)
@@ -231,14 +270,14 @@ def main():
 
     # With N > 1 the gather of step k's flag bytes (RCCL, its own stream) overlaps the check of step k+1:
     # two flag buffers, the collective asynchronous, waited for one step later and before the clock stops.
-    fbuf = [flags, torch.zeros_like(flags)] if world > 1 else [flags]
+    fbuf = [flags, torch.zeros_like(flags)] if sharded else [flags]
     pending = None
 
     def step(k):
         nonlocal pending
         f = fbuf[k % len(fbuf)]
         scene.check_batch_dev(qs[k % N_INPUTS], f, WHAT, stream)
-        if world > 1:
+        if sharded:
             if pending is not None:
                 pending.wait()
             pending = dist.all_gather_into_tensor(gathered, f, async_op=True)
@@ -250,7 +289,7 @@ def main():
         pending = None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -259,7 +298,7 @@ def main():
         ev[k][0].record()
         scene.check_batch_dev(qs[k % N_INPUTS], f, WHAT, stream)
         ev[k][1].record()
-        if world > 1:
+        if sharded:
             if pending is not None:
                 pending.wait()
             pending = dist.all_gather_into_tensor(gathered, f, async_op=True)
@@ -267,27 +306,34 @@ def main():
         pending.wait()
         pending = None
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     flags = fbuf[(args.steps - 1) % len(fbuf)]   # the buffer the last step wrote
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    # collision statistics (and a whole-job reduction when sharded)
+    # collision statistics and the instrumented run's counters; when sharded, ONE all-reduce(sum) makes them whole-job
+    # figures (collision, limit, cull and SAT counters)
     stats = torch.stack([(flags & 1).ne(0).sum(), (flags & 2).ne(0).sum(), (flags & 4).ne(0).sum()]).to(torch.int64)
-    if world > 1:
+    stats = torch.cat([stats, torch.tensor([counters["configs"], counters["cull_pass"], counters["sat_tests"], counters["exact_tests"]],
+                                           dtype=torch.int64, device=device)])
+    gather_ok = None
+    if sharded:
         dist.all_reduce(stats)
+        # the gathered buffer holds every rank's flags of the last step: this rank's slice must be its own bytes
+        gather_ok = bool((gathered[rank * B:(rank + 1) * B] == flags).all().item())
     total_configs = B * world * args.steps
     value = total_configs / elapsed
 
     if rank == 0:
-        achieved_tflops = flops_per_config * B / (kernel_ms * 1e-3) / 1e12
         peak = VALU_PEAK_TFLOPS[args.precision]
+        algorithmic_tflops = flops_per_config * B / (kernel_ms * 1e-3) / 1e12     # SURVEY 8d's formula: the reference's pair set
+        executed_tflops = executed_flops * B / (kernel_ms * 1e-3) / 1e12          # the arithmetic the kernels really run
         bytes_per_config = w.dof * (4 if args.precision == 32 else 8) + 1
         traffic = measured_traffic(B) if args.precision == 32 else None
         out = {
@@ -299,32 +345,42 @@ def main():
                        "robot_shapes": int(w.robot_keep.desc.n_shapes), "obstacles": int(w.obstacle_keep.desc.n_shapes),
                        "self_pairs": int(w.robot_keep.desc.n_pairs), "margin": w.margin,
                        "batch_per_gpu": B, "checks": "env+self+limit", "sharding": f"dp{world}, scene replicated",
-                       "collectives": "all_gather(flags) per step, overlapped with the next step" if world > 1 else "none"},
+                       "collectives": ("all_gather(flags) per step, overlapped with the next step; one all_reduce(sum) of the "
+                                       "collision / limit / cull / SAT counters; all_reduce(max) of the elapsed time") if sharded else "none",
+                       "forced_collectives": bool(args.force_collectives and world == 1),
+                       "gather_self_check": gather_ok},
             "roofline": {
                 "bound": "valu",
                 "kernel": "k_sweep_n1 (FK + broadphase + stage 1 of the narrow phase; dominant) + k_narrow2 (exact stage) + "
                           "k_check (hit words -> flag bytes), one launch of each per chunk of at most 4M configurations (four 2M "
                           "chunks per 8M step on four streams, two of 4M on one), chunks rotating over 4 streams from 6M configurations per call",
-                "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved_tflops / peak, "traffic": traffic,
-                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, profiles/r02/pipeline_traffic.json)",
+                # `achieved` / `frac`: arithmetic the kernels EXECUTE (FK + listed broadphase candidates + SAT + exact
+                # queries, priced as SURVEY 8d prices them) against the vector peak: a utilisation figure, <= 1 by
+                # construction.  The formula figure, which prices the reference's whole L x O pair set although the
+                # broadphase grid never executes it, is kept beside it as `algorithmic_*` (a speed-up-over-brute-force
+                # figure: it would pass 1.0 with a better grid).
+                "achieved": executed_tflops, "peak": peak, "unit": "TFLOP/s",
+                "frac": executed_tflops / peak,
+                "algorithmic_achieved": algorithmic_tflops, "algorithmic_frac": algorithmic_tflops / peak,
+                "valu_issue": measured_issue(),
+                "traffic": traffic,
+                "traffic_unit": "bytes per step (fabric reads + writes, rocprofv3 PMC, %s: a constant read from the committed "
+                                "profile, not measured in this run)" % os.path.relpath(TRAFFIC_JSON, ROOT),
                 "algorithmic_bytes": bytes_per_config * B,
                 "kernel_ms": kernel_ms, "algorithmic_flops_per_config": flops_per_config, "mix": mix,
                 "executed": {
                     "broadphase_candidates_per_config": cand_per_config, "flops_per_config": executed_flops,
-                    "TFLOPs": executed_flops * B / (kernel_ms * 1e-3) / 1e12,
-                    "frac": executed_flops * B / (kernel_ms * 1e-3) / 1e12 / peak,
-                    "note": "the broadphase grid replaces the L*O cull sweep that `achieved` prices (SURVEY 8d's "
-                            "formula) by a cell lookup: `achieved`/`frac` say how fast the reference's pair set is "
-                            "decided, this entry how busy the vector units are with arithmetic the formula counts"},
+                    "TFLOPs": executed_tflops, "frac": executed_tflops / peak},
                 "hbm_algorithmic_GBps": bytes_per_config * B / (kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
                 "hbm_traffic_GBps": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
                 "hbm_traffic_frac_of_peak": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "sustained_fma_TFLOPs_measured": {"3_waves_per_simd": 111.9, "8_waves_per_simd": 129.9,
-                                                  "source": "tools/valu_rate.hip, profiles/r01/valu_rate.txt"},
+                                                  "source": "tools/valu_rate.hip, profiles/r01/valu_rate.txt (constants from that file)"},
                 "note": "VALU-bound path (SURVEY 8d): the f32 vector peak equals the f32 MFMA peak; MFMA unused by "
                         "design.  kernel_ms = HIP events on the launch stream around one step (all kernels of the step)"},
+            "counters_all_reduced": {"instrumented_configs": int(stats[3].item()), "cull_pass": int(stats[4].item()),
+                                     "sat_tests": int(stats[5].item()), "exact_tests": int(stats[6].item())},
             "flag_rates": {"env": stats[0].item() / (B * world), "self": stats[1].item() / (B * world),
                            "limit": stats[2].item() / (B * world)},
         }
@@ -338,15 +394,16 @@ def main():
             out["free_space"] = side_measurement(W.metric_workload_sparse(args.obstacles), args.precision, B, device, stream,
                                                  side_steps, 1, 1234)
         if world == 1 and not args.no_cpu_baseline:
-            k = 0 if args.no_parity else 256
+            k = 0 if args.no_parity else min(args.parity_sample, B)
             q_last = qs[(args.steps - 1) % N_INPUTS]   # the input batch of the step that wrote `flags`
-            out["cpu_baseline"] = cpu_baseline(w, args.precision, q_last[:k].cpu().numpy() if k else None,
-                                               flags[:k].cpu().numpy() if k else None)
+            pick = torch.linspace(0, B - 1, max(k, 1), device=device, dtype=torch.float64).round().to(torch.int64) if k else None   # spread over every chunk
+            out["cpu_baseline"] = cpu_baseline(w, args.precision, q_last[pick].cpu().numpy() if k else None,
+                                               flags[pick].cpu().numpy() if k else None)
             spot = out["cpu_baseline"]["gpu_parity_spot_check"]
             if spot is not None and spot["outside"] != 0:   # the line is still printed: the record says what was measured
                 print(f"bench: WARNING: the timed step's flags differ from the oracle's outside the band: {spot}", file=sys.stderr)
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -50,6 +50,8 @@ def lib():
         L.orc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_distance_bounds.restype = C.c_double
         L.orc_distance_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_last_gjk.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_last_gjk.restype = None
         L.orc_project_simplex.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_cylinder_vertices.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_quat_from_rpy.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p]
@@ -72,6 +74,7 @@ class OracleScene:
         self.n_nodes = robot_keep.desc.n_nodes
         self.n_obstacles = obstacle_keep.desc.n_shapes
         self.n_pairs = robot_keep.desc.n_pairs
+        self.margin = float(np.float32(margin)) if precision == 32 else float(margin)   # CollisionChecker::prediction as T
         self.h = lib().orc_scene_create(C.addressof(robot_keep.desc), C.addressof(obstacle_keep.desc),
                                         margin, precision)
         if not self.h:
@@ -109,12 +112,15 @@ class OracleScene:
     GJK_EXITS = ("none", "zero_projection", "no_progress", "converged", "point_rejected", "tetra_closest",
                  "tetra_intersection", "iteration_cap")
 
-    def explain(self, q_row, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF, window=0.0, cap=256):
+    def explain(self, q_row, what=D.GH_CHECK_ENV | D.GH_CHECK_SELF, window=0.0, cap=None):
         """Every pair of ONE configuration that is within `window` of the margin or reported free without
-        its lower bound certifying it: list of dicts (self, id_a, id_b, kinds, d, lower, iters, exit)."""
+        its lower bound certifying it: list of dicts (self, id_a, id_b, kinds, d, lower, iters, exit).
+        window=inf lists every pair."""
         q = self._q(np.asarray(q_row).reshape(1, -1))
+        if cap is None:
+            cap = 256 if window < 1.0 else 1 << 17
         out = np.zeros((cap, 9), np.float64)
-        n = lib().orc_explain(self.h, _ptr(q), what, float(window), _ptr(out), cap)
+        n = lib().orc_explain(self.h, _ptr(q), what, float(min(window, 1e30)), _ptr(out), cap)
         recs = []
         for r in out[:min(n, cap)]:
             recs.append({"self": bool(r[0]), "id_a": int(r[1]), "id_b": int(r[2]),
@@ -169,6 +175,13 @@ def distance_bounds(spec_a: D.ShapeSpec, spec_b: D.ShapeSpec, precision: int = 6
     d = lib().orc_distance_bounds(C.addressof(sa), C.addressof(ma), C.addressof(sb), C.addressof(mb), precision,
                                   C.byref(lo))
     return d, lo.value
+
+
+def last_gjk():
+    """(iterations, exit reason) of the last GJK run made on this thread (OracleScene.GJK_EXITS names)."""
+    it, ex = C.c_int(0), C.c_int(0)
+    lib().orc_last_gjk(C.byref(it), C.byref(ex))
+    return it.value, OracleScene.GJK_EXITS[ex.value]
 
 
 def project_simplex(points) -> np.ndarray:

@@ -237,6 +237,12 @@ double orc_distance_bounds(const gh_shape_desc* a, const gh_mesh_desc* meshes_a,
   return distance(make_iso<double>(a->t, a->q), sa, make_iso<double>(b->t, b->q), sb, (Stats*)nullptr, lower);
 }
 
+// how the calling thread's last GJK run ended (gear_oracle::GjkExit) and after how many iterations
+void orc_last_gjk(int* iters, int* exit_reason) {
+  *iters = last_gjk().iters;
+  *exit_reason = last_gjk().exit;
+}
+
 // closest point to the origin on a simplex of n (1..4) points, through the
 // same Voronoi-region code GJK uses (unit tests vs brute force).
 int orc_project_simplex(const double* pts, int n, double* out) {

@@ -8,7 +8,8 @@ from gear_amd import descriptors as D
 from gear_amd import engine, urdf
 from gear_amd import workloads as W
 from oracle import binding as orc
-from tests.parity import POSE_TOL, certain, check_flags
+from tests import oracle_fixtures as F
+from tests.parity import POSE_TOL, certain, check_flags, check_flags_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -79,21 +80,32 @@ def test_flags_sample_urdf_arm_only(sample_robot, obstacles_robot, prec):
     _check_flags("flags_sample_urdf_arm_only", w, prec, 5000, seed=1, overshoot=0.02, what=D.GH_CHECK_ENV)
 
 
+def _fixture_flags(name, fixture, prec, what_extra=0):
+    fx = F.load(f"{fixture}_f{prec}")
+    w = fx["w"]
+    hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    return check_flags_fixture(f"{name}[f{prec}]", hip, fx, fx["spec"]["what"] | what_extra)
+
+
 @pytest.mark.parametrize("prec", [32, 64])
 def test_flags_metric_scene(prec):
-    _check_flags("flags_metric_scene", W.metric_workload(), prec, 4000, seed=2, overshoot=0.01)
+    # 16384 configurations of the metric scene against the committed oracle answers, on the default path (the
+    # single-launch kernel at this size) and through the pipeline
+    rep, got = _fixture_flags("flags_metric_scene", "metric", prec)
+    rep2, got2 = _fixture_flags("flags_metric_scene_pipeline", "metric", prec, D.GH_PATH_PIPELINE)
+    assert (got == got2).all()
 
 
 @pytest.mark.parametrize("prec", [32, 64])
 def test_flags_cylinder_obstacles(prec):
     # cylinder obstacles are reference-undefined (Compound::new rejects TriMesh); parity is against the
     # oracle's surface-distance definition
-    _check_flags("flags_cylinder_obstacles", W.ur10_workload(64), prec, 1500, seed=4)
+    _fixture_flags("flags_cylinder_obstacles", "cylinder_obstacles", prec)
 
 
 @pytest.mark.parametrize("prec", [32, 64])
 def test_flags_4096_obstacles(prec):
-    _check_flags("flags_4096_obstacles", W.sawyer_workload(4096), prec, 128, seed=5)   # the 640-configuration sample: test_gpu_configs.py
+    _fixture_flags("flags_4096_obstacles", "config3_4096", prec)     # default path; pipeline and fused: test_gpu_configs.py
 
 
 @pytest.mark.parametrize("prec", [32, 64])

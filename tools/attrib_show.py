@@ -31,3 +31,27 @@ att = {
     "limits + FK walk + shape poses (fk_only)": rows.get("fk_only", {}).get("SQ_INSTS_VALU"),
 }
 print(json.dumps(att, indent=1))
+# issue-side summary of the unablated kernel.  SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles (4 clocks);
+# a SIMD retires one wave64 VALU instruction per 2 clocks at its peak (157.3 TFLOP/s = 256 CU x 4 SIMD x 64 lanes x 2 flop
+# / 2 clocks x 2.4 GHz), one wave alone issues one per 4 clocks.
+if "full" in rows and len(sys.argv) > 3:
+    f, b = rows["full"], rows.get("busy", {})
+    waves_per_simd = int(sys.argv[3])
+    cyc = 4.0 * f["SQ_WAVE_CYCLES"]
+    issue = {
+        "kernel": kern, "waves_per_simd": waves_per_simd,
+        "valu_insts_per_wave": f["SQ_INSTS_VALU"], "salu_insts_per_wave": f["SQ_INSTS_SALU"],
+        "lds_insts_per_wave": f["SQ_INSTS_LDS"], "smem_insts_per_wave": f["SQ_INSTS_SMEM"],
+        "wave_cycles": cyc,
+        "valu_issue_frac": round(waves_per_simd * f["SQ_INSTS_VALU"] * 2.0 / cyc, 4),
+        "per_wave_time_split": {
+            "issuing (SQ_ACTIVE_INST_ANY)": round(b.get("SQ_ACTIVE_INST_ANY", 0) / f["SQ_WAVE_CYCLES"], 3),
+            "of which VALU (SQ_ACTIVE_INST_VALU)": round(f["SQ_ACTIVE_INST_VALU"] / f["SQ_WAVE_CYCLES"], 3),
+            "of which scalar (SQ_ACTIVE_INST_SCA)": round(b.get("SQ_ACTIVE_INST_SCA", 0) / f["SQ_WAVE_CYCLES"], 3),
+            "parked on s_waitcnt (SQ_WAIT_ANY)": round(f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"], 3),
+            "issue-stalled (SQ_WAIT_INST_ANY)": round(b.get("SQ_WAIT_INST_ANY", 0) / f["SQ_WAVE_CYCLES"], 3)},
+        "source": "rocprofv3 --pmc passes of tools/attrib_sweep.sh over tools/run_once.py (512k configurations, metric scene, f32, one stream)",
+    }
+    print(json.dumps({"issue": issue}, indent=1))
+    json.dump({"counters_per_wavefront": rows, "valu_attribution_per_wavefront": att, "issue": issue},
+              open(sys.argv[4], "w"), indent=1)
