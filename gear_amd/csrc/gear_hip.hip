@@ -17,6 +17,7 @@
 #include "../../include/gear_hip.h"
 #include "gear_kernels.hpp"
 #include "gear_small.hpp"
+#include "gear_edges.hpp"
 #include "gear_scene.hpp"
 
 using namespace gear_hip;
@@ -214,6 +215,7 @@ struct gh_scene {
   hipStream_t stream = nullptr;
   std::mutex mu;
   DevBuf q, flags, out, edges, store, first;
+  DevBuf ends, ecnt, ebsum;  // gh_check_edges_from_endpoints: end points, samples per edge, block totals of the scan
   PinBuf hq, hflags, hedges, hfirst;  // small host-buffer calls run on these in place
   // the pipeline's workspace sets are the device's (PipePool); consecutive chunks of one call take different
   // sets so that they can be in flight together (set 0 on the caller's stream, set k on aux[k])
@@ -928,6 +930,7 @@ void gh_scene_destroy(gh_scene* sc) {
     for (void* p : sc->tables) (void)hipFree(p);
     if (sc->counters) (void)hipFree(sc->counters);
     sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
+    sc->ends.release(); sc->ecnt.release(); sc->ebsum.release();
     sc->hq.release(); sc->hflags.release(); sc->hedges.release(); sc->hfirst.release(); sc->hseq.release();
     for (int k = 1; k < kMaxSets; k++) {
       if (sc->aux[k]) { (void)hipStreamSynchronize(sc->aux[k]); (void)hipStreamDestroy(sc->aux[k]); }
@@ -1237,6 +1240,123 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
     if (n) std::memcpy(flags, sc->hflags.p, n);
     std::memcpy(first_bad, sc->hfirst.p, n_edges * 4);
   }
+  return GH_OK;
+}
+
+// ---- edges from their end points (gear_edges.hpp) ---------------------------------------------------
+// Enqueues on `st`: samples per edge -> cnt_dev, their exclusive prefix sum -> off_dev[0..n_edges] (off_dev[n_edges] =
+// total).  The caller holds the scene's Guard.
+static int edges_count_scan(gh_scene* sc, const void* from_dev, const void* to_dev, size_t n_edges, double step,
+                            uint32_t max_len, uint32_t mode, uint32_t* cnt_dev, uint32_t* off_dev, hipStream_t st) {
+  const size_t n_blocks = (n_edges + 1023) / 1024;
+  int rc = sc->ebsum.ensure((n_blocks + 1) * 4);
+  if (rc) return rc;
+  const dim3 g256((unsigned)((n_edges + 255) / 256));
+  if (sc->precision == 32)
+    hipLaunchKernelGGL((k_edge_count<float>), g256, dim3(256), 0, st, (const float*)from_dev, (const float*)to_dev, n_edges, sc->D,
+                       (float)step, max_len, mode, cnt_dev);
+  else
+    hipLaunchKernelGGL((k_edge_count<double>), g256, dim3(256), 0, st, (const double*)from_dev, (const double*)to_dev, n_edges, sc->D,
+                       step, max_len, mode, cnt_dev);
+  hipLaunchKernelGGL(k_edge_scan1, dim3((unsigned)n_blocks), dim3(1024), 0, st, cnt_dev, n_edges, off_dev, (uint32_t*)sc->ebsum.p);
+  hipLaunchKernelGGL(k_edge_scan2, dim3(1), dim3(1024), 0, st, (uint32_t*)sc->ebsum.p, n_blocks);
+  hipLaunchKernelGGL(k_edge_scan3, dim3((unsigned)n_blocks), dim3(1024), 0, st, off_dev, n_edges, (const uint32_t*)sc->ebsum.p, n_blocks);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+static void edges_fill(gh_scene* sc, const void* from_dev, const void* to_dev, size_t n_edges, double step, uint32_t max_len,
+                       uint32_t mode, const uint32_t* off_dev, void* q_dev, hipStream_t st) {
+  const dim3 g256((unsigned)((n_edges + 255) / 256));
+  if (sc->precision == 32)
+    hipLaunchKernelGGL((k_edge_fill<float>), g256, dim3(256), 0, st, (const float*)from_dev, (const float*)to_dev, n_edges, sc->D,
+                       (float)step, max_len, mode, off_dev, (float*)q_dev);
+  else
+    hipLaunchKernelGGL((k_edge_fill<double>), g256, dim3(256), 0, st, (const double*)from_dev, (const double*)to_dev, n_edges, sc->D,
+                       step, max_len, mode, off_dev, (double*)q_dev);
+}
+
+static int edges_args_ok(const gh_scene* sc, double step, uint32_t max_len, uint32_t mode) {
+  if (!(step > 0)) return fail(GH_ERR_INVALID, "step must be positive");
+  if (max_len == 0 || max_len > (1u << 20)) return fail(GH_ERR_INVALID, "max_len must be in 1..1048576");
+  if (mode != GH_EDGE_CONNECT && mode != GH_EDGE_WALK) return fail(GH_ERR_INVALID, "mode must be GH_EDGE_CONNECT or GH_EDGE_WALK");
+  if (sc->D > kEdgeMaxDof) return fail(GH_ERR_TOO_LARGE, "edges from end points support at most 64 batch columns");
+  if (sc->D == 0) return fail(GH_ERR_DOF_MISMATCH, "scene has no batch columns");
+  return GH_OK;
+}
+
+int gh_check_edges_from_endpoints_dev(gh_scene* sc, const void* from_dev, const void* to_dev, size_t n_edges, double step,
+                                      uint32_t max_len, uint32_t mode, uint32_t what, uint8_t bad_mask, void* q_dev,
+                                      size_t cap_samples, uint32_t* edge_off_dev, uint32_t* n_samples_dev, uint8_t* flags_dev,
+                                      int32_t* first_bad_dev, size_t* total_samples, void* stream) {
+  if (sc && !sc->parts.empty()) return fail(GH_ERR_INVALID, "device-pointer entry points take a single-device scene");
+  if (!sc || !total_samples || (n_edges && (!from_dev || !to_dev || !edge_off_dev || !n_samples_dev || !first_bad_dev)))
+    return fail(GH_ERR_INVALID, "null argument");
+  *total_samples = 0;
+  if (n_edges == 0) return GH_OK;
+  if (n_edges >= (size_t(1) << 31)) return fail(GH_ERR_TOO_LARGE, "too many edges");
+  int rc = edges_args_ok(sc, step, max_len, mode);
+  if (rc) return rc;
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = stream ? (hipStream_t)stream : sc->stream;
+  if ((rc = edges_count_scan(sc, from_dev, to_dev, n_edges, step, max_len, mode, n_samples_dev, edge_off_dev, st))) return rc;
+  // the one synchronisation of this call: the number of samples decides buffer use and which kernels run
+  uint32_t total = 0;
+  GH_HIP(hipMemcpyAsync(&total, edge_off_dev + n_edges, 4, hipMemcpyDeviceToHost, st));
+  GH_HIP(hipStreamSynchronize(st));
+  *total_samples = total;
+  if (total > cap_samples)
+    return fail(GH_ERR_TOO_LARGE, "the edges have " + std::to_string(total) + " samples; q_dev / flags_dev hold " + std::to_string(cap_samples));
+  if (total && (!q_dev || !flags_dev)) return fail(GH_ERR_INVALID, "null argument");
+  edges_fill(sc, from_dev, to_dev, n_edges, step, max_len, mode, edge_off_dev, q_dev, st);
+  GH_HIP(hipGetLastError());
+  return check_edges_locked(sc, q_dev, edge_off_dev, n_edges, total, what, bad_mask, flags_dev, first_bad_dev, st);
+}
+
+int gh_check_edges_from_endpoints(gh_scene* sc, const void* from, const void* to, size_t n_edges, double step, uint32_t max_len,
+                                  uint32_t mode, uint32_t what, uint8_t bad_mask, int32_t* first_bad, uint32_t* n_samples) {
+  if (sc && !sc->parts.empty()) {
+    if (n_edges && (!from || !to || !first_bad || !n_samples)) return fail(GH_ERR_INVALID, "null argument");
+    if (n_edges <= kZeroCopyMax) return gh_check_edges_from_endpoints(sc->parts[0], from, to, n_edges, step, max_len, mode, what, bad_mask, first_bad, n_samples);
+    const size_t G = std::min<size_t>(sc->parts.size(), n_edges);  // equal shares of edges (their lengths are not known yet)
+    const size_t row = (size_t)sc->D * sc->elem();
+    return run_parts(sc, G, [&](size_t k) {
+      const size_t lo = n_edges * k / G, hi = n_edges * (k + 1) / G;
+      return gh_check_edges_from_endpoints(sc->parts[k], (const char*)from + lo * row, (const char*)to + lo * row, hi - lo, step,
+                                           max_len, mode, what, bad_mask, first_bad + lo, n_samples + lo);
+    });
+  }
+  if (!sc || (n_edges && (!from || !to || !first_bad || !n_samples))) return fail(GH_ERR_INVALID, "null argument");
+  if (n_edges == 0) return GH_OK;
+  if (n_edges >= (size_t(1) << 31)) return fail(GH_ERR_TOO_LARGE, "too many edges");
+  int rc = edges_args_ok(sc, step, max_len, mode);
+  if (rc) return rc;
+  Guard g(sc);
+  if (!g.ok) return fail(GH_ERR_HIP, "hipSetDevice failed");
+  const size_t eb = n_edges * (size_t)sc->D * sc->elem();
+  if ((rc = sc->ends.ensure(2 * eb)) || (rc = sc->ecnt.ensure(n_edges * 4)) || (rc = sc->edges.ensure((n_edges + 1) * 4)) ||
+      (rc = sc->first.ensure(n_edges * 4)))
+    return rc;
+  char* from_dev = (char*)sc->ends.p;
+  char* to_dev = from_dev + eb;
+  GH_HIP(hipMemcpyAsync(from_dev, from, eb, hipMemcpyHostToDevice, sc->stream));
+  GH_HIP(hipMemcpyAsync(to_dev, to, eb, hipMemcpyHostToDevice, sc->stream));
+  if ((rc = edges_count_scan(sc, from_dev, to_dev, n_edges, step, max_len, mode, (uint32_t*)sc->ecnt.p, (uint32_t*)sc->edges.p, sc->stream)))
+    return rc;
+  uint32_t total = 0;
+  GH_HIP(hipMemcpyAsync(&total, (uint32_t*)sc->edges.p + n_edges, 4, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipMemcpyAsync(n_samples, sc->ecnt.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
+  if ((rc = sc->q.ensure(std::max<size_t>((size_t)total * sc->D * sc->elem(), 1))) || (rc = sc->flags.ensure(std::max<size_t>(total, 1))))
+    return rc;
+  edges_fill(sc, from_dev, to_dev, n_edges, step, max_len, mode, (const uint32_t*)sc->edges.p, sc->q.p, sc->stream);
+  GH_HIP(hipGetLastError());
+  if ((rc = check_edges_locked(sc, sc->q.p, (const uint32_t*)sc->edges.p, n_edges, total, what, bad_mask, (uint8_t*)sc->flags.p,
+                               (int32_t*)sc->first.p, sc->stream, true)))
+    return rc;
+  GH_HIP(hipMemcpyAsync(first_bad, sc->first.p, n_edges * 4, hipMemcpyDeviceToHost, sc->stream));
+  GH_HIP(hipStreamSynchronize(sc->stream));
   return GH_OK;
 }
 

@@ -20,6 +20,7 @@ GH_SHAPE_BOX, GH_SHAPE_BALL, GH_SHAPE_CYLINDER, GH_SHAPE_MESH = 0, 1, 2, 3
 GH_FLAG_ENV, GH_FLAG_SELF, GH_FLAG_LIMIT = 1, 2, 4
 GH_CHECK_ENV, GH_CHECK_SELF = 1, 2
 GH_CHECK_NO_LIMITS = 0x10
+GH_EDGE_CONNECT, GH_EDGE_WALK, GH_EDGE_TRUNCATED = 0, 1, 0x80000000   # gh_check_edges_from_endpoints: stepping rule, n_samples bit 31
 GH_PATH_SMALL = 0x20
 GH_PATH_FUSED, GH_PATH_PIPELINE, GH_PATH_NO_GRID, GH_COUNT_CANDIDATES = 0x1000, 0x2000, 0x4000, 0x8000   # evaluation-path selection bits of `what` (same results)
 

@@ -21,6 +21,7 @@ SYMBOLS = [
     "gh_scene_device", "gh_check_batch", "gh_check_batch_dev", "gh_check_edges", "gh_check_edges_dev",
     "gh_fk_batch", "gh_fk_batch_dev", "gh_link_hits", "gh_link_mask_words", "gh_self_hits",
     "gh_check_batch_counted", "gh_check_batch_noalloc", "gh_pipeline_last_stats", "gh_last_error", "gh_version",
+    "gh_check_edges_from_endpoints", "gh_check_edges_from_endpoints_dev",
 ]
 
 
@@ -50,6 +51,9 @@ def lib():
         L.gh_check_batch_noalloc.argtypes = [vp, vp, sz, u32, vp, vp]
         L.gh_check_edges.argtypes = [vp, vp, vp, sz, u32, u8, vp, vp]
         L.gh_check_edges_dev.argtypes = [vp, vp, vp, sz, sz, u32, u8, vp, vp, vp]
+        L.gh_check_edges_from_endpoints.argtypes = [vp, vp, vp, sz, C.c_double, u32, u32, u32, u8, vp, vp]
+        L.gh_check_edges_from_endpoints_dev.argtypes = [vp, vp, vp, sz, C.c_double, u32, u32, u32, u8, vp, sz, vp, vp, vp, vp,
+                                                        C.POINTER(sz), vp]
         L.gh_fk_batch.argtypes = [vp, vp, sz, vp]
         L.gh_fk_batch_dev.argtypes = [vp, vp, sz, vp, vp]
         L.gh_link_hits.argtypes = [vp, vp, sz, u32, vp]
@@ -131,6 +135,18 @@ class Scene:
                                     _ptr(first_bad)))
         return flags, first_bad
 
+    def check_edges_from_endpoints(self, start, goal, step=0.1, max_len=4096, mode=D.GH_EDGE_CONNECT, what=D.GH_CHECK_ENV,
+                                   bad_mask=D.GH_FLAG_ENV | D.GH_FLAG_LIMIT):
+        """(first_bad[E], n_samples[E]) of the edges start[e] -> goal[e], their samples generated on the device."""
+        a, b = self._q(start), self._q(goal)
+        assert a.shape == b.shape
+        E = a.shape[0]
+        first_bad = np.full(E, -1, np.int32)
+        n_samples = np.zeros(E, np.uint32)
+        _check(lib().gh_check_edges_from_endpoints(self.h, _ptr(a), _ptr(b), E, float(step), int(max_len), int(mode), what, bad_mask,
+                                                   _ptr(first_bad), _ptr(n_samples)))
+        return first_bad, n_samples
+
     def fk_batch(self, q) -> np.ndarray:
         q = self._q(q)
         poses = np.zeros((q.shape[0], self.n_nodes, 7), self.dtype)
@@ -162,6 +178,18 @@ class Scene:
         n, E = q_t.shape[0], edge_off_t.numel() - 1
         _check(lib().gh_check_edges_dev(self.h, q_t.data_ptr(), edge_off_t.data_ptr(), E, n, what, bad_mask,
                                         flags_t.data_ptr(), first_bad_t.data_ptr(), stream))
+
+    def check_edges_from_endpoints_dev(self, from_t, to_t, q_t, edge_off_t, n_samples_t, flags_t, first_bad_t, step=0.1, max_len=4096,
+                                       mode=D.GH_EDGE_CONNECT, what=D.GH_CHECK_ENV, bad_mask=D.GH_FLAG_ENV | D.GH_FLAG_LIMIT,
+                                       stream: Optional[int] = None) -> int:
+        """Device arrays in, device arrays out; returns the number of samples written to q_t / flags_t."""
+        E = from_t.shape[0]
+        total = C.c_size_t(0)
+        _check(lib().gh_check_edges_from_endpoints_dev(self.h, from_t.data_ptr(), to_t.data_ptr(), E, float(step), int(max_len), int(mode),
+                                                       what, bad_mask, q_t.data_ptr(), q_t.shape[0], edge_off_t.data_ptr(),
+                                                       n_samples_t.data_ptr(), flags_t.data_ptr(), first_bad_t.data_ptr(),
+                                                       C.byref(total), stream))
+        return int(total.value)
 
     def fk_batch_dev(self, q_t, poses_t, stream: Optional[int] = None):
         _check(lib().gh_fk_batch_dev(self.h, q_t.data_ptr(), q_t.shape[0], poses_t.data_ptr(), stream))

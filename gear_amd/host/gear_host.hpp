@@ -680,6 +680,11 @@ class Scene {
     int rc = gh_check_batch(h_, q, n, what, flags);
     if (rc != GH_OK) throw gpu_error(rc);
   }
+  void check_edges_from_endpoints(const void* from, const void* to, size_t n_edges, double step, uint32_t max_len, uint32_t mode,
+                                  uint32_t what, uint8_t bad_mask, int32_t* first_bad, uint32_t* n_samples) const {
+    int rc = gh_check_edges_from_endpoints(h_, from, to, n_edges, step, max_len, mode, what, bad_mask, first_bad, n_samples);
+    if (rc != GH_OK) throw gpu_error(rc);
+  }
   void check_edges(const void* q, const uint32_t* edge_off, size_t n_edges, uint32_t what, uint8_t bad_mask, uint8_t* flags, int32_t* first_bad) const {
     int rc = gh_check_edges(h_, q, edge_off, n_edges, what, bad_mask, flags, first_bad);
     if (rc != GH_OK) throw gpu_error(rc);
@@ -793,6 +798,18 @@ template <class N> void connect_line(const N* from, const N* target, size_t dim,
     out.insert(out.end(), nxt.begin(), nxt.end());
     if (distance(nxt.data(), target, dim) < extend_length) return;  // ExtendStatus::Reached
     cur = nxt;
+  }
+}
+
+// the samples smooth_path's walker evaluates from `from` towards `target`, assuming all are free: it advances by
+// extend_length while it is at least extend_length away; the target itself is not evaluated
+template <class N> void walk_line(const N* from, const N* target, size_t dim, N extend_length, std::vector<N>& out) {
+  std::vector<N> base(from, from + dim), nxt(dim);
+  while (!(distance(base.data(), target, dim) < extend_length)) {
+    const N d = distance(base.data(), target, dim);
+    for (size_t i = 0; i < dim; i++) nxt[i] = base[i] + (target[i] - base[i]) * extend_length / d;
+    out.insert(out.end(), nxt.begin(), nxt.end());
+    base = nxt;
   }
 }
 
@@ -934,14 +951,8 @@ void smooth_path(std::vector<std::vector<N>>& path, const LineEval<N>& eval, N e
       const size_t ind2 = r.range(ind1 + 2, path.size());
       // the samples the trial's loop evaluates while they stay free; it ends when the walker is
       // within extend_length of path[ind2]
-      std::vector<N> base(path[ind1]), nxt(dim);
       const uint32_t begin = (uint32_t)(q.size() / dim);
-      while (!(distance(base.data(), path[ind2].data(), dim) < extend_length)) {
-        const N d = distance(base.data(), path[ind2].data(), dim);
-        for (size_t i = 0; i < dim; i++) nxt[i] = base[i] + (path[ind2][i] - base[i]) * extend_length / d;
-        q.insert(q.end(), nxt.begin(), nxt.end());
-        base = nxt;
-      }
+      walk_line(path[ind1].data(), path[ind2].data(), dim, extend_length, q);
       trials.push_back({ind1, ind2, begin, (uint32_t)(q.size() / dim), r});
       off.push_back((uint32_t)(q.size() / dim));
     }
@@ -1073,6 +1084,23 @@ template <class N> class JointPathPlanner {
         .check_edges(q.data(), off.data(), off.size() - 1, with_self ? GH_CHECK_SELF : GH_CHECK_ENV,
                      (uint8_t)((with_self ? GH_FLAG_SELF : GH_FLAG_ENV) | GH_FLAG_LIMIT), f.data(), bad.data());
     return bad;
+  }
+
+  // A large batch of straight edges given by their end points (from, to: [n_edges][dof]); the samples rrt's stepping
+  // would evaluate are generated on the device (gh_check_edges_from_endpoints).  mode GH_EDGE_CONNECT: Tree::connect
+  // lines; GH_EDGE_WALK: smooth_path shortcuts.  Returns per edge {first infeasible sample or -1, sample count}.
+  // For bulk validation (thousands of edges): plan() itself keeps host-side stepping, which is faster for a few lines.
+  std::pair<std::vector<int32_t>, std::vector<uint32_t>> first_infeasible_from_endpoints(
+      const std::vector<int>& using_joints, const std::vector<N>& from, const std::vector<N>& to, uint32_t mode, const Compound* objects,
+      bool with_self, uint32_t max_len = 1u << 16) {
+    const size_t n = using_joints.empty() ? 0 : from.size() / using_joints.size();
+    if (to.size() != from.size()) throw Error(Error::DofMismatch, "from and to differ in length");
+    std::vector<int32_t> bad(n, -1);
+    std::vector<uint32_t> cnt(n, 0);
+    scene(using_joints, with_self ? nullptr : objects)
+        .check_edges_from_endpoints(from.data(), to.data(), n, (double)step_length, max_len, mode, with_self ? GH_CHECK_SELF : GH_CHECK_ENV,
+                                    (uint8_t)((with_self ? GH_FLAG_SELF : GH_FLAG_ENV) | GH_FLAG_LIMIT), bad.data(), cnt.data());
+    return {bad, cnt};
   }
 
   // Plan the sequence of joint angles of `using_joints` (:144-190)

@@ -332,6 +332,46 @@ const char* gp_joint_names(gp_planner* p) {
   return box->text.c_str();
 }
 
+// ---- rrt 0.4.0's stepping, as the host layer restates it (test support: the device replay of
+// gh_check_edges_from_endpoints must give these samples bit for bit) ----
+int gp_edge_line(const double* from, const double* to, int dim, double step, int precision, int mode, double* out, int cap_rows) {
+  return guarded([&]() -> int {
+    int rows;
+    if (precision == 32) {
+      std::vector<float> q;
+      auto a = to_vec<float>(from, dim), b = to_vec<float>(to, dim);
+      if (mode == GH_EDGE_WALK) rrt::walk_line<float>(a.data(), b.data(), (size_t)dim, (float)step, q);
+      else rrt::connect_line<float>(a.data(), b.data(), (size_t)dim, (float)step, q);
+      rows = (int)(q.size() / (size_t)dim);
+      for (int i = 0; i < std::min(rows, cap_rows) * dim; i++) out[i] = (double)q[(size_t)i];
+    } else {
+      std::vector<double> q;
+      if (mode == GH_EDGE_WALK) rrt::walk_line<double>(from, to, (size_t)dim, step, q);
+      else rrt::connect_line<double>(from, to, (size_t)dim, step, q);
+      rows = (int)(q.size() / (size_t)dim);
+      for (int i = 0; i < std::min(rows, cap_rows) * dim; i++) out[i] = q[(size_t)i];
+    }
+    return rows;
+  });
+}
+
+int gp_first_infeasible_from_endpoints(gp_planner* p, const int32_t* using_joints, int n_using, const double* from, const double* to,
+                                       size_t n_edges, int mode, const gp_compound* objects, int with_self, int32_t* first_bad,
+                                       uint32_t* n_samples) {
+  GP_BOX(p);
+  const Compound* c = reinterpret_cast<const Compound*>(objects);
+  return guarded([&]() -> int {
+    const int n = (int)(n_edges * (size_t)n_using);
+    auto r = GP_DISPATCH(box->p32->first_infeasible_from_endpoints(using_vec(using_joints, n_using), to_vec<float>(from, n), to_vec<float>(to, n),
+                                                                   (uint32_t)mode, c, with_self != 0),
+                         box->p64->first_infeasible_from_endpoints(using_vec(using_joints, n_using), to_vec<double>(from, n), to_vec<double>(to, n),
+                                                                   (uint32_t)mode, c, with_self != 0));
+    std::memcpy(first_bad, r.first.data(), n_edges * sizeof(int32_t));
+    std::memcpy(n_samples, r.second.data(), n_edges * sizeof(uint32_t));
+    return GP_OK;
+  });
+}
+
 // ---- src/funcs.rs helpers, callable without a planner (host arithmetic only: no GPU involved) ----
 namespace {
 Limits limits_from_c(const double* lo, const double* hi, const uint8_t* has, int n) {

@@ -23,7 +23,7 @@ SYMBOLS = [
     "gp_is_feasible_batch", "gp_plan", "gp_plan_avoid_self_collision", "gp_last_collision_names",
     "gp_feasible_ik_seeds", "gp_joint_positions", "gp_joint_names",
     "gp_generate_clamped_joint_positions_from_limits", "gp_generate_random_joint_positions_from_limits",
-    "gp_modify_to_nearest_angle",
+    "gp_modify_to_nearest_angle", "gp_edge_line", "gp_first_infeasible_from_endpoints",
 ]
 
 GP_ERR = {-10: "CollisionStart", -11: "CollisionEnd", -12: "SelfCollisionStart", -13: "SelfCollisionEnd",
@@ -76,6 +76,9 @@ def lib():
         L.gp_generate_clamped_joint_positions_from_limits.argtypes = [dp, C.c_int, dp, dp, u8p, C.c_int, C.c_int, dp]
         L.gp_generate_random_joint_positions_from_limits.argtypes = [dp, dp, u8p, C.c_int, C.c_int, C.c_uint64, C.c_size_t, dp]
         L.gp_modify_to_nearest_angle.argtypes = [dp, dp, C.c_int, dp, dp, u8p, C.c_int]
+        L.gp_edge_line.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int, dp, C.c_int]
+        L.gp_first_infeasible_from_endpoints.argtypes = [vp, i32p, C.c_int, dp, dp, C.c_size_t, C.c_int, vp, C.c_int,
+                                                         i32p, C.POINTER(C.c_uint32)]
         _LIB = L
     return _LIB
 
@@ -133,6 +136,17 @@ def modify_to_nearest_angle(vec1, vec2, limits, precision: int = 64) -> np.ndarr
                                             lo.ctypes.data_as(C.POINTER(C.c_double)), hi.ctypes.data_as(C.POINTER(C.c_double)),
                                             has.ctypes.data_as(C.POINTER(C.c_uint8)), precision))
     return b
+
+
+def edge_line(start, goal, step: float, precision: int, mode: int = D.GH_EDGE_CONNECT, cap: int = 4096) -> np.ndarray:
+    """The samples rrt's stepping evaluates between two configurations, by the C++ host layer."""
+    a, ap = _f64(start)
+    b, bp = _f64(goal)
+    out = np.zeros((cap, len(a)), np.float64)
+    n = lib().gp_edge_line(ap, bp, len(a), step, precision, mode, out.ctypes.data_as(C.POINTER(C.c_double)), cap)
+    _raise(n)
+    assert n <= cap
+    return out[:n].copy()
 
 
 class HostCompound:
@@ -233,6 +247,17 @@ class HostPlanner:
         self._check(lib().gp_is_feasible_batch(self.h, up, len(u), ap, a.shape[0], objects.h if objects else None,
                                                int(with_self), ok.ctypes.data_as(C.POINTER(C.c_uint8))))
         return ok.astype(bool)
+
+    def first_infeasible_from_endpoints(self, using, start, goal, objects: Optional[HostCompound], mode=D.GH_EDGE_CONNECT, with_self=False):
+        u, up = _i32(using)
+        a, ap = _f64(start)
+        b, bp = _f64(goal)
+        first = np.zeros(a.shape[0], np.int32)
+        cnt = np.zeros(a.shape[0], np.uint32)
+        self._check(lib().gp_first_infeasible_from_endpoints(self.h, up, len(u), ap, bp, a.shape[0], mode, objects.h if objects else None,
+                                                             int(with_self), first.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                             cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return first, cnt
 
     def _plan(self, fn, using, start, goal, objects):
         u, up = _i32(using)

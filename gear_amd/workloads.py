@@ -219,6 +219,53 @@ def straight_edges(chain: U.Chain, using: Sequence[int], n_edges: int, seed: int
     return np.asarray(qs, dtype=dtype), np.asarray(off, np.uint32)
 
 
+def edge_samples_lockstep(a: np.ndarray, b: np.ndarray, step: float, mode: int = D.GH_EDGE_CONNECT, max_len: int = 1 << 20):
+    """The samples rrt 0.4.0's stepping evaluates on the edges a[e] -> b[e], all edges advanced in
+    lockstep with numpy in the arrays' dtype: the iterated recurrence  d = sqrt(sum_i (cur_i - b_i)^2) (summed in index
+    order), next = cur + (b - cur) * step / d.  mode GH_EDGE_CONNECT: Tree::connect (a step that would overshoot lands on
+    b; the line ends with the first sample within `step` of b); GH_EDGE_WALK: smooth_path's walker (advance while at least
+    `step` away; b itself is not a sample).  Returns (q [n][D], off [E + 1]); an edge is cut after max_len samples."""
+    dtype = a.dtype.type
+    n_edges, dim = a.shape
+    stp = dtype(step)
+
+    def dist(x, y):
+        s = np.zeros(len(x), dtype)
+        for c in range(dim):                      # in index order, one rounding per term: what the scalar loops do
+            t = x[:, c] - y[:, c]
+            s = s + t * t
+        return np.sqrt(s)
+
+    cur = a.copy()
+    alive = np.ones(n_edges, bool)
+    count = np.zeros(n_edges, np.int64)
+    rows = []
+    while alive.any():
+        ids = np.nonzero(alive)[0]
+        d = dist(cur[ids], b[ids])
+        near = d < stp
+        if mode == D.GH_EDGE_WALK:
+            alive[ids[near]] = False
+            ids, d, near = ids[~near], d[~near], near[~near]
+            if len(ids) == 0:
+                break
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nxt = cur[ids] + (b[ids] - cur[ids]) * stp / d[:, None]
+        nxt = np.where(near[:, None], b[ids], nxt).astype(dtype)
+        rows.append((ids, count[ids].copy(), nxt))
+        cur[ids] = nxt
+        count[ids] += 1
+        if mode == D.GH_EDGE_CONNECT:
+            done = near | (dist(nxt, b[ids]) < stp)
+            alive[ids[done]] = False
+        alive[ids[count[ids] >= max_len]] = False
+    off = np.concatenate([[0], np.cumsum(count)]).astype(np.uint32)
+    q = np.empty((int(off[-1]), dim), dtype)
+    for ids, k, smp in rows:
+        q[off[ids] + k] = smp
+    return q, off
+
+
 def convex_mesh(rng, scale, n_min=8, n_max=24):
     """A random closed convex triangle mesh (<= 64 vertices): the hull of points on a squashed sphere."""
     from scipy.spatial import ConvexHull

@@ -234,6 +234,34 @@ int gh_check_edges_dev(gh_scene* scene, const void* q_dev, const uint32_t* edge_
                        size_t n_edges, size_t n_samples, uint32_t what, uint8_t bad_mask,
                        uint8_t* flags_dev, int32_t* first_bad_dev, void* hip_stream);
 
+/* Edge batches from their END POINTS.  No counterpart in the reference as a function: it is the stepping of
+ * rrt 0.4.0 that the reference's closure is called from (joint_path_planner.rs:168-188; restated in
+ * gear_amd/host/gear_host.hpp connect_line / smooth_path), replayed on the device so that a large batch of edges
+ * crosses PCIe as 2 x D values per edge instead of sample by sample.  One lane per edge runs the ITERATED recurrence
+ *     d = sqrt(sum_i (cur_i - to_i)^2);   next_i = cur_i + (to_i - cur_i) * step / d
+ * in the scene's precision with IEEE division and square root and no contraction: the samples are bit-identical to
+ * the host stepping's (tests/test_gpu_edges_endpoints.py).  mode:
+ *   GH_EDGE_CONNECT  Tree::connect: extend() repeatedly until a sample lies within `step` of `to`; a step that
+ *                    would overshoot lands on `to` itself;
+ *   GH_EDGE_WALK     smooth_path's walker: advance by `step` while at least `step` away from `to`; `to` itself is
+ *                    not a sample (an edge shorter than `step` has none).
+ * from, to: [n_edges][D].  first_bad[e]: as gh_check_edges.  n_samples[e]: samples of edge e; bit 31
+ * (GH_EDGE_TRUNCATED) is set when the edge had not ended after max_len samples — its first max_len samples were
+ * evaluated.  Meant for LARGE batches: for an RRT line or two the host computes the samples faster than one lane
+ * does (the recurrence is serial), which is why the planner of gear_host.hpp keeps gh_check_edges for its calls.
+ * The _dev form takes device arrays; the samples are written to q_dev (capacity cap_samples rows, as are flags_dev's
+ * bytes), their offsets to edge_off_dev[n_edges + 1]; it synchronises `hip_stream` ONCE (the sample count decides
+ * what is launched) and reports the count in *total_samples (GH_ERR_TOO_LARGE if it exceeds cap_samples). */
+enum { GH_EDGE_CONNECT = 0, GH_EDGE_WALK = 1 };
+#define GH_EDGE_TRUNCATED 0x80000000u
+int gh_check_edges_from_endpoints(gh_scene* scene, const void* from, const void* to, size_t n_edges, double step,
+                                  uint32_t max_len, uint32_t mode, uint32_t what, uint8_t bad_mask,
+                                  int32_t* first_bad, uint32_t* n_samples);
+int gh_check_edges_from_endpoints_dev(gh_scene* scene, const void* from_dev, const void* to_dev, size_t n_edges,
+                                      double step, uint32_t max_len, uint32_t mode, uint32_t what, uint8_t bad_mask,
+                                      void* q_dev, size_t cap_samples, uint32_t* edge_off_dev, uint32_t* n_samples_dev,
+                                      uint8_t* flags_dev, int32_t* first_bad_dev, size_t* total_samples, void* hip_stream);
+
 /* Replaces k::Chain::set_joint_positions + update_transforms as used at
  * collision_checker.rs:54,124 and joint_path_planner.rs:245-247.
  * poses: [n][N][7] = tx,ty,tz,qi,qj,qk,qw of every node's world transform.

@@ -107,6 +107,19 @@ int gp_feasible_ik_seeds(gp_planner* p, const int32_t* using_joints, int n_using
 int gp_joint_positions(gp_planner* p, const int32_t* using_joints, int n_using, double* q);
 const char* gp_joint_names(gp_planner* p);
 
+/* rrt 0.4.0's stepping as the host layer restates it (gear_host.hpp connect_line / walk_line): the samples one
+ * Tree::connect line (mode GH_EDGE_CONNECT) or one smooth_path walk (GH_EDGE_WALK) evaluates between `from` and
+ * `to`, in precision 32|64, assuming all are free.  out: [cap_rows][dim]; returns the number of samples (which may
+ * exceed cap_rows).  Test support for gh_check_edges_from_endpoints. */
+int gp_edge_line(const double* from, const double* to, int dim, double step, int precision, int mode, double* out, int cap_rows);
+
+/* Bulk validation of straight edges given by their end points (from, to: [n_edges][n_using]) with the planner's step
+ * length: the first infeasible sample of every edge (or -1) and its sample count, the samples generated on the device
+ * (gh_check_edges_from_endpoints).  The batched form of the closure calls at joint_path_planner.rs:168-188. */
+int gp_first_infeasible_from_endpoints(gp_planner* p, const int32_t* using_joints, int n_using, const double* from,
+                                       const double* to, size_t n_edges, int mode, const gp_compound* objects,
+                                       int with_self, int32_t* first_bad, uint32_t* n_samples);
+
 /* src/funcs.rs helpers, pure host arithmetic (no planner, no GPU).  Limits cross as three arrays:
  * has_limit[i] != 0 <=> Some(Range::new(lo[i], hi[i])), else None.  precision 32|64 = the type parameter T
  * the arithmetic runs in; values cross as double.

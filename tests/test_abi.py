@@ -74,6 +74,7 @@ def test_constants_match_header():
     text = open(os.path.join(ROOT, "include", "gear_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     header = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\b(GH_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))", text)}
+    header.update({m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(GH_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)u?\b", text)})
     assert {"GH_CHECK_ENV", "GH_CHECK_SELF", "GH_CHECK_NO_LIMITS", "GH_PATH_SMALL", "GH_PATH_FUSED", "GH_PATH_PIPELINE",
             "GH_PATH_NO_GRID", "GH_COUNT_CANDIDATES", "GH_FLAG_ENV", "GH_FLAG_SELF", "GH_FLAG_LIMIT", "GH_SHAPE_MESH"} <= set(header)
     named = {k: v for k, v in vars(D).items() if k.startswith("GH_") and isinstance(v, int)}
