@@ -739,7 +739,12 @@ struct Stats {
   uint64_t iterations = 0;    // dual_rrt_connect loop iterations
   uint64_t shortcuts = 0;     // smoothing shortcuts applied
   uint64_t eval_ns = 0;       // wall time spent inside the evaluator (staging, launch, synchronisation)
+  uint64_t draw_ns = 0;       // wall time spent drawing iterations ahead: random samples, nearest-vertex lookups, stepping
+  uint64_t apply_ns = 0;      // wall time spent consuming the evaluated iterations (validation against the grown trees, tree growth)
 };
+inline uint64_t now_ns() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // Evaluates lines of samples: `q` holds all samples row-major, line e = rows [off[e], off[e+1]).
 // Returns per line the index of its first infeasible sample, or -1.
@@ -790,26 +795,46 @@ template <class N> void step_towards(const N* from, const N* target, size_t dim,
   for (size_t i = 0; i < dim; i++) out[i] = from[i] + (target[i] - from[i]) * extend_length / d;
 }
 
-// the samples `connect` would evaluate from vertex `from` towards `target`, assuming all are free
+// the samples `connect` would evaluate from vertex `from` towards `target`, assuming all are free: extend() after
+// extend(), each from the vertex the last one added, until one lands within extend_length of the target.
+// (extend() measures the distance to the target twice per step — before stepping and, for ExtendStatus::Reached,
+// after it; the second measurement of one step IS the first of the next, same operands, same operations, so it
+// is computed once here: the samples are bit for bit those of the step-by-step form.)
 template <class N> void connect_line(const N* from, const N* target, size_t dim, N extend_length, std::vector<N>& out) {
-  std::vector<N> cur(from, from + dim), nxt(dim);
+  size_t at = out.size();
+  out.resize(at + dim);
+  N d = distance(from, target, dim);
+  {
+    N* nxt = out.data() + at;
+    if (d < extend_length) std::copy(target, target + dim, nxt);
+    else for (size_t i = 0; i < dim; i++) nxt[i] = from[i] + (target[i] - from[i]) * extend_length / d;
+  }
   for (;;) {
-    step_towards(cur.data(), target, dim, extend_length, nxt.data());
-    out.insert(out.end(), nxt.begin(), nxt.end());
-    if (distance(nxt.data(), target, dim) < extend_length) return;  // ExtendStatus::Reached
-    cur = nxt;
+    d = distance(out.data() + at, target, dim);
+    if (d < extend_length) return;  // ExtendStatus::Reached
+    out.resize(at + 2 * dim);
+    const N* cur = out.data() + at;
+    N* nxt = out.data() + at + dim;
+    for (size_t i = 0; i < dim; i++) nxt[i] = cur[i] + (target[i] - cur[i]) * extend_length / d;  // (d >= extend_length here)
+    at += dim;
   }
 }
 
 // the samples smooth_path's walker evaluates from `from` towards `target`, assuming all are free: it advances by
 // extend_length while it is at least extend_length away; the target itself is not evaluated
 template <class N> void walk_line(const N* from, const N* target, size_t dim, N extend_length, std::vector<N>& out) {
-  std::vector<N> base(from, from + dim), nxt(dim);
-  while (!(distance(base.data(), target, dim) < extend_length)) {
-    const N d = distance(base.data(), target, dim);
-    for (size_t i = 0; i < dim; i++) nxt[i] = base[i] + (target[i] - base[i]) * extend_length / d;
-    out.insert(out.end(), nxt.begin(), nxt.end());
-    base = nxt;
+  N d = distance(from, target, dim);
+  size_t at = out.size();
+  std::vector<N> first(from, from + dim);  // `from` may point into `out`
+  bool have = false;
+  while (!(d < extend_length)) {
+    out.resize(at + dim);
+    const N* c = have ? out.data() + at - dim : first.data();
+    N* nxt = out.data() + at;
+    for (size_t i = 0; i < dim; i++) nxt[i] = c[i] + (target[i] - c[i]) * extend_length / d;
+    d = distance(nxt, target, dim);
+    at += dim;
+    have = true;
   }
 }
 
@@ -848,6 +873,7 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
   const size_t ahead = std::max<size_t>(lookahead, 1);
   size_t it = 0;
   while (it < num_max_try) {
+    const uint64_t t_draw = now_ns();
     std::vector<Iter> iters;
     Rng r = rng;
     Tree<N>*ka = a, *kb = b;
@@ -866,6 +892,7 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
       iters.push_back(std::move(x));
       std::swap(ka, kb);
     }
+    st.draw_ns += now_ns() - t_draw;
     std::vector<int32_t> bad;  // per iteration: [extend sample, line]
     if (lookahead > 0) {
       std::vector<N> q;
@@ -890,6 +917,7 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
     // is still the sequential algorithm's as long as its two nearest-vertex lookups come out the same on the
     // grown trees (then its extend sample and its connect line are the same too).  The first iteration for
     // which they do not ends the batch: the random source goes back to its state before that iteration.
+    const uint64_t t_apply = now_ns();
     size_t last = 0;
     bool grown = false;
     Tree<N>* const a0 = a;  // the tree whose size was size_a0
@@ -918,12 +946,14 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
         a_all.insert(a_all.end(), b_all.begin(), b_all.end());
         if (std::strcmp(b->name, "start") == 0) std::reverse(a_all.begin(), a_all.end());
         rng = x.after;
+        st.apply_ns += now_ns() - t_apply;
         return a_all;
       }
       std::swap(a, b);
       grown = true;
     }
     rng = iters[last].after;
+    st.apply_ns += now_ns() - t_apply;
   }
   throw Error(Error::PathPlanFail, "failed");
 }

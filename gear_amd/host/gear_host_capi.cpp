@@ -80,6 +80,7 @@ int plan_t(JointPathPlanner<N>& p, PlannerBox* box, const int32_t* u, int n_usin
   if (stats) {
     stats[0] = p.stats.gpu_calls; stats[1] = p.stats.samples; stats[2] = p.stats.consumed;
     stats[3] = p.stats.iterations; stats[4] = p.stats.shortcuts; stats[5] = p.stats.eval_ns;
+    stats[6] = p.stats.draw_ns; stats[7] = p.stats.apply_ns;
   }
   if (rc != GP_OK) return rc;
   *rows = (int)out.size();

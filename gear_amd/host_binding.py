@@ -272,7 +272,7 @@ class HostPlanner:
             rc = fn(self.h, up, len(u), sp, gp, pp, cap, C.byref(rows), stats)
         else:
             rc = fn(self.h, up, len(u), sp, gp, objects.h, pp, cap, C.byref(rows), stats)
-        self.last_stats = dict(zip(("gpu_calls", "samples", "consumed", "iterations", "shortcuts", "eval_ns"), [int(x) for x in stats]))
+        self.last_stats = dict(zip(("gpu_calls", "samples", "consumed", "iterations", "shortcuts", "eval_ns", "draw_ns", "apply_ns"), [int(x) for x in stats]))
         self._check(rc)
         return path[:rows.value].copy()
 

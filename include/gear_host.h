@@ -89,7 +89,8 @@ int gp_is_feasible_batch(gp_planner* p, const int32_t* using_joints, int n_using
  * start/goal validation, rrt::dual_rrt_connect, rrt::smooth_path.  path: [cap_rows][n_using], *rows
  * receives the number of way points.  stats (may be NULL): [0] GPU calls, [1] samples sent,
  * [2] samples the sequential algorithm consumes, [3] RRT iterations, [4] shortcuts applied,
- * [5] nanoseconds spent inside the GPU evaluator (room for 8 values).
+ * [5] nanoseconds spent inside the GPU evaluator, [6] drawing RRT iterations ahead (random samples, nearest-vertex
+ * lookups, stepping), [7] consuming them (8 values).
  * On GP_ERR_(SELF_)COLLISION_* gp_last_collision_names() holds the error's collision_link_names. */
 int gp_plan(gp_planner* p, const int32_t* using_joints, int n_using, const double* start, const double* goal,
             const gp_compound* objects, double* path, int cap_rows, int* rows, uint64_t* stats);

@@ -141,3 +141,4 @@ def test_generate_random_joint_positions_from_limits(funcs_golden):
         assert np.all(a[:, 1] >= -1.0) and np.all(a[:, 1] < 1.0)
         assert np.all(a[:, 2] >= 0.0) and np.all(a[:, 2] < 0.1 + (1e-8 if precision == 32 else 0.0))
         assert a[:, 0].min() < -2.5 and a[:, 0].max() > 2.5                # the whole circle is drawn from
+
