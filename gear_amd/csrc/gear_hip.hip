@@ -113,7 +113,8 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 struct Knobs {
   size_t pipe_chunk = size_t(4) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass (at most; a call's chunks are equal)
   int pipe_streams = kMaxSets;          // GEAR_HIP_PIPE_STREAMS: 1 keeps every chunk on the caller's stream
-  size_t exact_cap = 0;                 // GEAR_HIP_EXACT_CAP: exact entries per sweep wavefront (tests force re-checks with it)
+  size_t exact_cap = 0;                 // GEAR_HIP_EXACT_CAP: exact entries per sweep wavefront, fixed (tests force re-checks with it)
+  size_t exact_cap0 = 0;                // GEAR_HIP_EXACT_CAP0: ... to start with; grows as usual when regions run full (tests)
   bool zero_copy = true;                // GEAR_HIP_ZERO_COPY=0: host-buffer calls always copy (measuring aid)
   bool sweep_clds = true;               // GEAR_HIP_SWEEP_CLDS=0: cull table never in LDS
   int sweep_waves = 0;                  // GEAR_HIP_SWEEP_WAVES: wavefronts per sweep workgroup (0: chosen by LDS use)
@@ -133,6 +134,7 @@ struct Knobs {
     x = num("GEAR_HIP_PIPE_STREAMS", kMaxSets);
     k.pipe_streams = (int)(x < 1 ? 1 : x > kMaxSets ? kMaxSets : x);
     k.exact_cap = (size_t)std::max<long long>(0, num("GEAR_HIP_EXACT_CAP", 0));
+    k.exact_cap0 = (size_t)std::max<long long>(0, num("GEAR_HIP_EXACT_CAP0", 0));
     k.zero_copy = num("GEAR_HIP_ZERO_COPY", 1) != 0;
     k.sweep_clds = num("GEAR_HIP_SWEEP_CLDS", 1) != 0;
     k.sweep_waves = (int)num("GEAR_HIP_SWEEP_WAVES", 0);
@@ -225,6 +227,8 @@ struct gh_scene {
   hipEvent_t ev_h2d[2] = {}, ev_d2h[2] = {};  // large host-buffer calls: a piece's input is in / its flags are out (made on first use)
   int last_sets = 0;  // workspace sets the last pipeline call used
   unsigned exact_cap = 128;  // exact entries per sweep wavefront before the fused path takes the wavefront over
+  unsigned exact_cap0 = 128; // ... as the scene was created with (the no-allocation entry point never grows it)
+  PinBuf hover;              // a host word a sweep wavefront sets when its exact region ran full: the next call doubles exact_cap
   bool has_mesh = false;
   Knobs knobs;
   CountersDev* counters = nullptr;
@@ -307,9 +311,14 @@ int build_and_upload(gh_scene* sc, const gh_robot_desc& r, const gh_obstacle_des
   // re-checked by the fused kernel (GEAR_HIP_EXACT_CAP overrides: tests force that).
   sc->has_mesh = !H.verts.empty();
   {
-    size_t cap = sc->has_mesh ? 512 : 128;
+    // 256 with meshes / 128 without: twice what the busiest measured scene fills (profiles/r03/exact_cap.txt: 42-120
+    // entries per wavefront on average over five scenes, no full region in 16384 wavefronts at these capacities; the
+    // round-2 sizes, 512 / 128, reserved 12x the mean).  An input distribution that needs more is noticed — a wavefront
+    // whose region runs full says so in a host word — and the capacity doubles for the scene's later calls.
+    size_t cap = sc->has_mesh ? 256 : 128;
+    if (sc->knobs.exact_cap0) cap = sc->knobs.exact_cap0;
     if (sc->knobs.exact_cap) cap = sc->knobs.exact_cap;
-    sc->exact_cap = (unsigned)std::min<size_t>(std::max<size_t>(cap, 1), 4096);
+    sc->exact_cap = sc->exact_cap0 = (unsigned)std::min<size_t>(std::max<size_t>(cap, 1), 4096);
   }
   return GH_OK;
 }
@@ -467,7 +476,16 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const bool do_env = (what & 1u) && S.n_obs > 0;
   const SweepPlan sp = plan_sweep<T>(sc, S, do_env, do_self);
   if (!sp.ok) return fail(GH_ERR_TOO_LARGE, "internal: pipeline chosen for a scene whose sweep does not fit the LDS");
-  const unsigned capw = sc->exact_cap;
+  // a wavefront of an earlier call on this scene found its exact region full (it was re-checked by the fused path: slow,
+  // not wrong): later calls get twice the room.  Tests that force a capacity (GEAR_HIP_EXACT_CAP) keep it.
+  if (!fixed && sc->hover.p && !sc->knobs.exact_cap) {
+    volatile unsigned* note = (volatile unsigned*)sc->hover.p;
+    if (*note != 0 && sc->exact_cap < 2048) {
+      *note = 0;
+      sc->exact_cap *= 2;
+    }
+  }
+  const unsigned capw = fixed ? sc->exact_cap0 : sc->exact_cap;
   // keep a chunk's exact arrays under 3 GiB (they are reserved for the worst case and touched only where entries
   // are written: capacity, not traffic; a 2M chunk of a scene with meshes and self pairs is 1.2 GiB in f32,
   // 2.3 GiB in f64)
@@ -503,6 +521,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     PipeWs<T>& W = Ws[0];
     W = PipeWs<T>{};
     W.capw = capw;
+    W.note = nullptr;
     W.hit = (unsigned*)fixed->take(chunk * 4);
     W.xcnt = (unsigned*)fixed->take(waves * 4);
     W.xkey = (uint2*)fixed->take(waves * capw * 8);
@@ -532,6 +551,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     if (b.used) GH_HIP(hipStreamWaitEvent(k ? sc->aux[k] : st, b.last_use, 0));
     W = PipeWs<T>{};
     W.capw = capw;
+    W.note = (unsigned*)sc->hover.d;
     if ((rc = b.hit.ensure(chunk * 4)) || (rc = b.xcnt.ensure(waves * 4)) || (rc = b.xkey.ensure(waves * capw * 8)) ||
         (rc = b.xpose_a.ensure(waves * capw * 8 * sizeof(T))) ||
         (do_self && (rc = b.xpose_b.ensure(waves * capw * 8 * sizeof(T)))) ||
@@ -872,6 +892,7 @@ int gh_scene_create(const gh_robot_desc* robot, const gh_obstacle_desc* obstacle
           rc = fail(GH_ERR_HIP, "counter allocation failed");
         else sc->small_done = reinterpret_cast<unsigned*>(sc->counters + 1);
       }
+      if (rc == GH_OK && (rc = sc->hover.ensure(64)) == GH_OK) std::memset(sc->hover.p, 0, 64);
     }
   }
   if (rc != GH_OK) {
@@ -931,7 +952,7 @@ void gh_scene_destroy(gh_scene* sc) {
     if (sc->counters) (void)hipFree(sc->counters);
     sc->q.release(); sc->flags.release(); sc->out.release(); sc->edges.release(); sc->store.release(); sc->first.release();
     sc->ends.release(); sc->ecnt.release(); sc->ebsum.release();
-    sc->hq.release(); sc->hflags.release(); sc->hedges.release(); sc->hfirst.release(); sc->hseq.release();
+    sc->hq.release(); sc->hflags.release(); sc->hedges.release(); sc->hfirst.release(); sc->hseq.release(); sc->hover.release();
     for (int k = 1; k < kMaxSets; k++) {
       if (sc->aux[k]) { (void)hipStreamSynchronize(sc->aux[k]); (void)hipStreamDestroy(sc->aux[k]); }
       if (sc->ev_join[k]) (void)hipEventDestroy(sc->ev_join[k]);

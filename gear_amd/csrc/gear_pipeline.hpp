@@ -61,6 +61,7 @@ template <class T> struct PipeWs {
   T* fq;            // [waves][n_first][64][4] rotation of every shape that is the earlier one of a self pair (same)
   PipeCounters* pc;
   unsigned capw;
+  unsigned* note;   // host word (as the device addresses it; may be null): set when a wavefront's exact region ran full
 };
 
 // One ring / pose record = 8 T (32 B in f32, 64 B in f64), written and read with 16-byte accesses.
@@ -446,6 +447,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
     unsigned out = !ok ? 4u : ((env_hit ? 1u : 0u) | (self_hit ? 2u : 0u));
     if (xover) out |= kHitRedo;
+    if (xover && lane == 0 && wave_live && W.note) __hip_atomic_store(W.note, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (live) W.hit[wave * kWave + lane] = out;
     if (lane == 0 && wave_live) W.xcnt[wave] = xover ? 0u : xcount;
   }

@@ -581,6 +581,7 @@ std::vector<N> generate_clamped_joint_positions_from_limits(const std::vector<N>
 // funcs.rs:76-87: (max - min) * u + min, or (u - 0.5) * 2 pi without a Range
 template <class N> std::vector<N> generate_random_joint_positions_from_limits(const Limits& limits, Rng& rng) {
   std::vector<N> v;
+  v.reserve(limits.size());
   for (auto& l : limits) {
     if (l.first) v.push_back(((N)l.second.max - (N)l.second.min) * (N)rng.uniform() + (N)l.second.min);
     else v.push_back((N)(rng.uniform() - 0.5) * (N)(2.0 * 3.14159265358979323846));
@@ -875,6 +876,7 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
   while (it < num_max_try) {
     const uint64_t t_draw = now_ns();
     std::vector<Iter> iters;
+    iters.reserve(ahead);
     Rng r = rng;
     Tree<N>*ka = a, *kb = b;
     const size_t size_a0 = a->size(), size_b0 = b->size();  // the trees the speculation looked at
@@ -886,6 +888,7 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
       x.q_new.resize(dim);
       step_towards(ka->at(x.near_a), q_rand.data(), dim, extend_length, x.q_new.data());
       x.near_b = kb->get_nearest_index(x.q_new.data());
+      x.line.reserve(dim * 64);
       connect_line(kb->at(x.near_b), x.q_new.data(), dim, extend_length, x.line);
       x.m = (uint32_t)(x.line.size() / dim);
       x.after = r;
@@ -897,6 +900,10 @@ std::vector<std::vector<N>> dual_rrt_connect(const std::vector<N>& start, const 
     if (lookahead > 0) {
       std::vector<N> q;
       std::vector<uint32_t> off{0u};
+      size_t rows = 0;
+      for (auto& x : iters) rows += 1 + x.m;
+      q.reserve(rows * dim);
+      off.reserve(2 * iters.size() + 1);
       for (auto& x : iters) {
         q.insert(q.end(), x.q_new.begin(), x.q_new.end());
         off.push_back(off.back() + 1);

@@ -171,3 +171,27 @@ def test_sweep_workgroup_shapes_agree():
                 {"GEAR_HIP_PIPE_CHUNK": 8192}):
         hip = _scene_with_env(w, 32, **env)
         assert (hip.check_batch(q, BOTH) == ref).all(), env
+
+
+def test_exact_capacity_grows_when_regions_run_full():
+    """A sweep wavefront whose exact region runs full says so in a host word, and the scene's later calls get twice the
+    room: from a deliberately small start (GEAR_HIP_EXACT_CAP0=16) the capacity doubles call by call until no region
+    is full any more; the flags are the same at every capacity."""
+    w = W.metric_workload()
+    q = w.configs(200000, seed=38, overshoot=0.01)
+    ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    want = ref.check_batch(q, BOTH | D.GH_PATH_FUSED)
+    assert (ref.check_batch(q, BOTH | D.GH_PATH_PIPELINE) == want).all()
+    assert ref.pipeline_last_stats()["exact_cap"] == 256                 # the default with meshes (URDF cylinders)
+    hip = _scene_with_env(w, 32, GEAR_HIP_EXACT_CAP0=16)
+    caps, full = [], []
+    for _ in range(7):
+        got = hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE | D.GH_COUNT_CANDIDATES)
+        assert (got == want).all()
+        st = hip.pipeline_last_stats()
+        caps.append(st["exact_cap"])
+        full.append(st["redo_waves"])
+    print("capacity per call", caps, "full regions", full)
+    assert caps[0] == 16 and caps[1] == 32 and caps[2] == 64 and caps[-1] in (128, 256)
+    assert full[0] > 1000 and full[-1] == 0
+    assert caps[-1] == caps[-2]                                          # it stops growing once nothing is full
