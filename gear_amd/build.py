@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgear_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in
-           ("gear_hip.hip", "gear_kernels.hpp", "gear_pipeline.hpp", "gear_small.hpp", "gear_edges.hpp", "gear_device.hpp", "gear_scene.hpp", "gear_types.hpp")]
+           ("gear_hip.hip", "gear_kernels.hpp", "gear_pipeline.hpp", "gear_small.hpp", "gear_edges.hpp", "gear_shard.hpp", "gear_device.hpp", "gear_scene.hpp", "gear_types.hpp")]
 HEADER = os.path.join(_HERE, "..", "include", "gear_hip.h")
 
 

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -18,6 +19,7 @@
 #include "gear_kernels.hpp"
 #include "gear_small.hpp"
 #include "gear_edges.hpp"
+#include "gear_shard.hpp"
 #include "gear_scene.hpp"
 
 using namespace gear_hip;
@@ -805,6 +807,80 @@ int run_parts(gh_scene* sc, size_t n_parts, F&& body) {  // body(k) -> status; e
 
 }  // namespace
 
+// ---- copies out of PAGEABLE host memory ------------------------------------------------------------------
+// hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread: 24-27 GB/s on the GPU box, half of what
+// the bus carries from page-locked memory (profiles/r02/host_buffers.txt).  A large batch from pageable memory is therefore
+// copied into the scene's page-locked staging by FOUR host threads (the caller and three helpers that the library keeps
+// parked between calls) one piece ahead of the bus, and crosses the bus from there.
+namespace {
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool* p = new CopyPool;  // never destroyed: its threads only ever touch host memory, and are parked at exit
+    return *p;
+  }
+  // dst[0, bytes) = src[0, bytes); returns when done.  One copy at a time (large host-buffer calls queue here).
+  void copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < (size_t(1) << 20) || !ok_) { std::memcpy(dst, src, bytes); return; }
+    std::lock_guard<std::mutex> one(call_mu_);
+    const size_t slice = (bytes / (kHelpers + 1) + 4095) & ~size_t(4095);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes; slice_ = slice;
+      pending_ = kHelpers;
+      generation_++;
+    }
+    cv_.notify_all();
+    std::memcpy(dst, src, std::min(slice, bytes));  // the caller's own slice
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  static constexpr int kHelpers = 3;
+  CopyPool() {
+    try {
+      for (int k = 0; k < kHelpers; k++) std::thread([this, k] { run(k + 1); }).detach();
+      ok_ = true;
+    } catch (const std::system_error&) {
+      ok_ = false;  // no threads to be had: plain memcpy
+    }
+  }
+  void run(int k) {
+    unsigned seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return generation_ != seen; });
+      seen = generation_;
+      char* d = dst_; const char* s = src_;
+      const size_t lo = std::min(bytes_, slice_ * (size_t)k), hi = std::min(bytes_, slice_ * (size_t)(k + 1));
+      lk.unlock();
+      if (hi > lo) std::memcpy(d + lo, s + lo, hi - lo);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex call_mu_, mu_;
+  std::condition_variable cv_, done_;
+  char* dst_ = nullptr;
+  const char* src_ = nullptr;
+  size_t bytes_ = 0, slice_ = 0;
+  int pending_ = 0;
+  unsigned generation_ = 0;
+  bool ok_ = false;
+};
+
+// is this host pointer page-locked memory the device can read directly (hipHostMalloc / hipHostRegister)?
+bool is_page_locked(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error: clear it
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
 // A large host-buffer batch, the scene's Guard held: device staging sc->q / sc->flags and page-locked sc->hflags are
 // ensured by the caller.  Inputs travel in pieces of kHostPiece on a stream of their own (a copy out of pageable memory
 // returns when the runtime has staged it: the device evaluates piece i meanwhile); the flags come back into
@@ -819,12 +895,25 @@ static int host_pieces(gh_scene* sc, const void* q, size_t n, uint32_t what, uin
     if (!sc->ev_d2h[k]) GH_HIP(hipEventCreateWithFlags(&sc->ev_d2h[k], hipEventDisableTiming));
   }
   const size_t row = (size_t)sc->D * sc->elem();
+  // pieces of 1M configurations; a batch of less than 4M is cut into four (at least 256k each) so that it overlaps too
+  const size_t piece = n >= 4 * kHostPiece ? kHostPiece : std::max<size_t>(kStagedMax, ((n + 3) / 4 + 65535) / 65536 * 65536);
   hipStream_t in = sc->aux[kMaxSets - 1];
   size_t prev_off = 0, prev_cnt = 0;
   int i = 0;
-  for (size_t off = 0; off < n; off += kHostPiece, i++) {
-    const size_t cnt = std::min(kHostPiece, n - off);
-    GH_HIP(hipMemcpyAsync((char*)sc->q.p + off * row, (const char*)q + off * row, cnt * row, hipMemcpyHostToDevice, in));
+  // pageable source: pieces go through two page-locked staging slots, filled by the copy pool while the previous piece is
+  // on the bus (slot i & 1 is free again once the copy recorded in ev_h2d[i & 1] two pieces ago has finished)
+  const bool staged = !is_page_locked(q);
+  if (staged && (rc = sc->hq.ensure(2 * piece * row))) return rc;
+  for (size_t off = 0; off < n; off += piece, i++) {
+    const size_t cnt = std::min(piece, n - off);
+    const char* src = (const char*)q + off * row;
+    if (staged) {
+      char* slot = (char*)sc->hq.p + (size_t)(i & 1) * piece * row;
+      if (i >= 2) GH_HIP(hipEventSynchronize(sc->ev_h2d[i & 1]));
+      CopyPool::get().copy(slot, src, cnt * row);
+      src = slot;
+    }
+    GH_HIP(hipMemcpyAsync((char*)sc->q.p + off * row, src, cnt * row, hipMemcpyHostToDevice, in));
     GH_HIP(hipEventRecord(sc->ev_h2d[i & 1], in));
     GH_HIP(hipStreamWaitEvent(sc->stream, sc->ev_h2d[i & 1], 0));
     if ((rc = check_dev(sc, (char*)sc->q.p + off * row, cnt, what, (uint8_t*)sc->flags.p + off, sc->stream, false))) {
@@ -1026,7 +1115,8 @@ int gh_check_batch(gh_scene* sc, const void* q, size_t n, uint32_t what, uint8_t
     const size_t G = std::min<size_t>(sc->parts.size(), std::max<size_t>(n, 1));
     const size_t row = (size_t)sc->D * sc->elem();
     return run_parts(sc, G, [&](size_t k) {
-      const size_t lo = n * k / G, hi = n * (k + 1) / G;
+      size_t lo, hi;
+      shard_range(n, k, G, &lo, &hi);
       return gh_check_batch(sc->parts[k], (const char*)q + lo * row, hi - lo, what, flags + lo);
     });
   }
@@ -1166,10 +1256,7 @@ int gh_check_edges(gh_scene* sc, const void* q, const uint32_t* edge_off, size_t
     // contiguous shares of whole edges, balanced by samples: share k starts at the first edge whose
     // first sample is at or beyond n * k / G
     const size_t G = std::min<size_t>(sc->parts.size(), n_edges);
-    std::vector<size_t> cut(G + 1, n_edges);
-    cut[0] = 0;
-    for (size_t k = 1; k < G; k++)
-      cut[k] = std::max<size_t>(cut[k - 1], (size_t)(std::lower_bound(edge_off, edge_off + n_edges, (uint32_t)(n * k / G)) - edge_off));
+    const std::vector<size_t> cut = shard_edges(edge_off, n_edges, G);
     const size_t row = (size_t)sc->D * sc->elem();
     return run_parts(sc, G, [&](size_t k) -> int {
       const size_t e0 = cut[k], e1 = cut[k + 1];
@@ -1343,7 +1430,8 @@ int gh_check_edges_from_endpoints(gh_scene* sc, const void* from, const void* to
     const size_t G = std::min<size_t>(sc->parts.size(), n_edges);  // equal shares of edges (their lengths are not known yet)
     const size_t row = (size_t)sc->D * sc->elem();
     return run_parts(sc, G, [&](size_t k) {
-      const size_t lo = n_edges * k / G, hi = n_edges * (k + 1) / G;
+      size_t lo, hi;
+      shard_range(n_edges, k, G, &lo, &hi);
       return gh_check_edges_from_endpoints(sc->parts[k], (const char*)from + lo * row, (const char*)to + lo * row, hi - lo, step,
                                            max_len, mode, what, bad_mask, first_bad + lo, n_samples + lo);
     });
@@ -1396,7 +1484,8 @@ int gh_fk_batch(gh_scene* sc, const void* q, size_t n, void* poses) {
     const size_t G = std::min<size_t>(sc->parts.size(), std::max<size_t>(n, 1));
     const size_t row = (size_t)sc->D * sc->elem(), prow = (size_t)sc->N * 7 * sc->elem();
     return run_parts(sc, G, [&](size_t k) {
-      const size_t lo = n * k / G, hi = n * (k + 1) / G;
+      size_t lo, hi;
+      shard_range(n, k, G, &lo, &hi);
       return gh_fk_batch(sc->parts[k], (const char*)q + lo * row, hi - lo, (char*)poses + lo * prow);
     });
   }

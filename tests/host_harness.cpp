@@ -6,6 +6,7 @@
 
 #include "../gear_amd/csrc/gear_device.hpp"
 #include "../gear_amd/csrc/gear_scene.hpp"
+#include "../gear_amd/csrc/gear_shard.hpp"
 
 using namespace gear_hip;
 
@@ -48,4 +49,12 @@ extern "C" int hh_pair_within(const gh_shape_desc* a, const gh_mesh_desc* ma, in
                               const gh_mesh_desc* mb, int nmb, double margin, int precision) {
   return precision == 32 ? run_pair<float>(a, ma, nma, b, mb, nmb, margin)
                          : run_pair<double>(a, ma, nma, b, mb, nmb, margin);
+}
+
+// the device group's sharding arithmetic (gear_shard.hpp): share k of G of n configurations
+extern "C" void hh_shard_range(size_t n, size_t k, size_t G, size_t* lo, size_t* hi) { shard_range(n, k, G, lo, hi); }
+// cut points of G shares of whole edges; cut: [G + 1]
+extern "C" void hh_shard_edges(const uint32_t* edge_off, size_t n_edges, size_t G, size_t* cut) {
+  const std::vector<size_t> c = shard_edges(edge_off, n_edges, G);
+  for (size_t k = 0; k <= G; k++) cut[k] = c[k];
 }

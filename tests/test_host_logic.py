@@ -106,3 +106,35 @@ def test_shard_edges_keep_edges_whole():
             assert e_lo == prev_e and s_lo == prev_s and s_lo == off[e_lo] and s_hi == off[e_hi]
             prev_e, prev_s = e_hi, s_hi
         assert prev_e == 500 and prev_s == off[-1]
+
+
+def test_device_group_sharding_arithmetic():
+    """gh_scene_create_multi's shares (gear_amd/csrc/gear_shard.hpp, compiled for the host): contiguous, covering the
+    batch exactly once, whole edges only, balanced by samples — for every share count a node can have and for the
+    awkward sizes (fewer configurations or edges than shares, empty edges, one giant edge)."""
+    from tests import harness
+    for n in (0, 1, 2, 7, 8, 9, 4097, 100001, (1 << 23) + 5):
+        for G in (1, 2, 3, 4, 8, 64):
+            g = min(G, max(n, 1))                                   # the library never makes more shares than configurations
+            prev = 0
+            sizes = []
+            for k in range(g):
+                lo, hi = harness.shard_range(n, k, g)
+                assert lo == prev and hi >= lo
+                prev = hi
+                sizes.append(hi - lo)
+            assert prev == n and max(sizes) - min(sizes) <= 1        # exact cover, balanced to one configuration
+    rng = np.random.default_rng(4)
+    cases = [rng.integers(0, 65, 1000), np.array([0, 0, 5, 0, 0]), np.array([100000, 1, 1, 1]), np.array([3]), np.zeros(6, int),
+             rng.integers(8, 65, 65536)]
+    for lens in cases:
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        E, n = len(lens), int(off[-1])
+        for G in (1, 2, 3, 8):
+            g = min(G, E)
+            cut = harness.shard_edges(off, g)
+            assert cut[0] == 0 and cut[-1] == E and (np.diff(cut) >= 0).all()       # whole edges, in order, all of them
+            samples = off[cut[1:]].astype(np.int64) - off[cut[:-1]].astype(np.int64)
+            assert samples.sum() == n
+            if E >= 8 * g and lens.max() <= 64:                      # many short edges: balanced to within one edge per share
+                assert samples.max() - samples.min() <= 2 * 64

@@ -47,6 +47,42 @@ for B in sizes:
             hip.hipHostFree(pq)
             hip.hipHostFree(pf)
 
+# a device group (gh_scene_create_multi) on this one-GPU box: the device listed twice and four times, i.e. the group's host
+# threads, per-share streams, staging and workspace sets, all on one device (no second GPU to add its own PCIe link and CUs)
+for devs in ([0, 0], [0, 0, 0, 0]):
+    grp = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32, devices=devs)
+    B = 1 << 23
+    q0 = w.configs(B, seed=3)
+    for pinned in (False, True):
+        if pinned:
+            pq, pf = C.c_void_p(), C.c_void_p()
+            assert hip.hipHostMalloc(C.byref(pq), C.c_size_t(q0.nbytes), 0) == 0
+            assert hip.hipHostMalloc(C.byref(pf), C.c_size_t(B), 0) == 0
+            q = np.ctypeslib.as_array(C.cast(pq, C.POINTER(C.c_float)), shape=q0.shape)
+            q[:] = q0
+            flags = np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_uint8)), shape=(B,))
+        else:
+            q, flags = q0, np.zeros(B, dtype=np.uint8)
+
+        def gcall():
+            rc = engine.lib().gh_check_batch(grp.h, q.ctypes.data_as(C.c_void_p), B, D.GH_CHECK_ENV | D.GH_CHECK_SELF,
+                                             flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+            assert rc == 0, rc
+
+        for _ in range(2):
+            gcall()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gcall()
+        dt = (time.perf_counter() - t0) / 5
+        print(f"device group {devs} host buffers {'page-locked' if pinned else 'pageable   '} B={B:8d}: {dt * 1e3:8.3f} ms  {B / dt / 1e9:6.3f} G configs/s"
+              f"  ({B * 29 / dt / 1e9:5.1f} GB/s over the bus)", flush=True)
+        if pinned:
+            del q, flags
+            hip.hipHostFree(pq)
+            hip.hipHostFree(pf)
+    del grp
+
 # gh_check_edges, mid-size: segments of 16..64 samples
 for n_edges in (256, 2048, 8192):
     qe, off = w.edges(n_edges, seed=41, dtype=np.float32, min_len=16, max_len=64)
