@@ -9,7 +9,7 @@
  * CollisionChecker::check_env / check_self
  * (src/collision/collision_checker.rs:268-287).  Each entry point below names
  * the reference item it replaces.  A Rust `-sys` crate binds exactly these
- * symbols.
+ * symbols (tests/test_abi.py checks that the library exports every one of them).
  *
  * Conventions
  *  - every function returns GH_OK (0) or a negative gh_status; nothing throws
@@ -83,7 +83,8 @@ enum {
  * holds; only is_feasible* goes through set_joint_positions (:77,:114).
  * Every entry point ignores bits of `what` that are not declared in this header. */
 enum { GH_CHECK_ENV = 1, GH_CHECK_SELF = 2, GH_CHECK_NO_LIMITS = 0x10 };
-/* optional `what` bits that only choose HOW the batch is evaluated; the result
+/* ---- diagnostics: nothing below is needed to use the library ------------------------------------------------
+ * Optional `what` bits that only choose HOW the batch is evaluated; the result
  * bytes are identical either way (tests/test_gpu_pipeline.py, tests/test_gpu_small.py).
  * Without them a call of up to 16384 configurations (6144 in f64) takes the single-launch
  * small-batch kernel (a configuration's work spread over many lanes: the RRT
@@ -218,8 +219,12 @@ int gh_check_batch_dev(gh_scene* scene, const void* q_dev, size_t n, uint32_t wh
  * until the process ends; its address on a device is looked up when a scene is created on that device.
  * Limits: n <= 65536, and the workspace this scene needs for n configurations must fit the 64 MiB
  * (GH_ERR_TOO_LARGE otherwise, with the number of configurations that do fit).  Every call on a GPU, from
- * any scene, uses that GPU's one array: calls that overlap in time on one GPU race — serialise them (one
- * stream, or events).  gh_pipeline_last_stats does not see these calls. */
+ * any scene, uses that GPU's one array.  The library orders them: an event per device is recorded behind each
+ * call and the next call's stream waits for it, so calls made one after the other — from one scene or several,
+ * on the scenes' own streams (hip_stream = NULL) or the caller's — never overlap on the array.  Calls enqueued
+ * at the same time from several host threads run in the order they took the library's lock.  The exact-stage
+ * capacity is the one the scene was created with (it does not grow here).  gh_pipeline_last_stats does not
+ * see these calls. */
 int gh_check_batch_noalloc(gh_scene* scene, const void* q_dev, size_t n, uint32_t what,
                            uint8_t* flags_dev, void* hip_stream);
 

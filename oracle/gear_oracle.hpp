@@ -24,6 +24,16 @@
 // against them.  Numeric distances, GJK tolerances and f64 behaviour beyond
 // those lists are PARITY UNPINNED and are covered by analytic known answers
 // (tests/test_oracle_analytic.py).
+// Two [recalled] details that no reference fixture pins, stated here so that nobody has to find them in the code:
+//   - GJK's iteration cap.  SURVEY a6 recalls "non-convergence after 100 iterations returns 0" for the distance query;
+//     gjk_closest_points below gives up after 10 000.  Neither count is ever reached on the convex polytopes and balls
+//     of this path (the other exits fire within ~40 iterations), so the choice cannot change a flag.
+//   - VoronoiSimplex::add_point refuses a support point by ABSOLUTE thresholds (eps_tol = 10 * EPSILON on a squared
+//     length, a squared cross product, a plane offset).  In f32 (eps_tol = 1.19e-6) that ends GJK runs on small balls
+//     after 2-9 iterations with an upper bound millimetres above the true distance: the f32 oracle then reports "free"
+//     with the margin inside its own certified interval [lower, d].  tests/parity.py calls such a mismatch
+//     `oracle_uncertified` (the SECOND stated parity band), tests/test_oracle_uncertified.py constructs it
+//     on purpose, and last_gjk() below says how every run ended.
 #pragma once
 
 #include <algorithm>
