@@ -78,6 +78,9 @@ def path(name):
 def load(name):
     """The stored oracle answers of fixture `name` plus its regenerated inputs: dict(spec, w, q, off, flags, band, ...)."""
     spec = SPECS[name]
+    if not os.path.exists(path(name)):   # a fixture still being generated must not take the rest of the suite down with it
+        import pytest
+        pytest.skip(f"tests/golden/oracle_{name}.npz is missing: python tests/golden/make_oracle_fixtures.py {name}")
     q, off = inputs(spec)
     z = np.load(path(name), allow_pickle=False)
     fx = {k: z[k] for k in z.files}
