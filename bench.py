@@ -64,7 +64,8 @@ def measured_issue():
     try:
         with open(ISSUE_JSON) as f:
             t = json.load(f)
-        return {k: t["issue"][k] for k in ("valu_issue_frac", "valu_insts_per_wave", "wave_cycles", "source")}
+        return {k: t["issue"][k] for k in ("valu_issue_frac", "valu_busy_cost_weighted_estimate", "valu_insts_per_wave", "wave_cycles", "source")
+                if k in t["issue"]}
     except (OSError, KeyError, ValueError):
         return None
 
