@@ -353,7 +353,7 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "kernel": "k_sweep_n1 (FK + broadphase + stage 1 of the narrow phase; dominant) + k_narrow2 (exact stage) + "
-                          "k_check (hit words -> flag bytes), one launch of each per chunk of at most 4M configurations (four 2M "
+                          "k_check (re-check of sweep wavefronts whose exact region ran full: normally none; the exact stage writes the flag bytes), one launch of each per chunk of at most 4M configurations (four 2M "
                           "chunks per 8M step on four streams, two of 4M on one), chunks rotating over 4 streams from 6M configurations per call",
                 # `achieved` / `frac`: arithmetic the kernels EXECUTE (FK + listed broadphase candidates + SAT + exact
                 # queries, priced as SURVEY 8d prices them) against the vector peak: a utilisation figure, <= 1 by

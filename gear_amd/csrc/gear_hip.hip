@@ -387,7 +387,8 @@ template <class T, int K>
 void launch_check_k(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t cnt, uint32_t what, uint8_t* flags,
                     hipStream_t st, bool counted, const StorePlan& plan, void* gs, size_t gstride, const unsigned* hit) {
   const size_t lds = plan.lds_bytes + queue_bytes(K);
-  const dim3 grid(grid_for(cnt)), block(kWave);
+  // (hit: the per-block re-check marks of the pipeline; a workgroup then looks at 64 of them)
+  const dim3 grid(hit ? (grid_for(cnt) + kWave - 1) / kWave : grid_for(cnt)), block(kWave);
   if (plan.global) {
     if (counted) hipLaunchKernelGGL((k_check<T, true, true, K>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride, hit);
     else hipLaunchKernelGGL((k_check<T, false, true, K>), grid, block, lds, st, S, q, cnt, what, flags, sc->counters, (T*)gs, gstride, hit);
@@ -584,7 +585,9 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
     const size_t cnt = std::min(chunk, n - off);
     const T* qc = q + off * sc->D;
     const int set = (int)(ci % (size_t)n_sets);
-    const PipeWs<T>& W = Ws[set];
+    PipeWs<T>& W = Ws[set];
+    W.flags = flags + off;
+    W.n_cfg = (unsigned)cnt;
     hipStream_t cs = set ? sc->aux[set] : st;
     if ((what & 0x8000u) || sc->knobs.n2_hist) GH_HIP(hipMemsetAsync(W.pc, 0, sizeof(PipeCounters), cs));
     const unsigned n_sw = grid_for(cnt);  // sweep wavefronts
@@ -630,7 +633,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
         else go(k_narrow2<T, false, false, 16>, 0);
       }
     }
-    launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.hit);
+    launch_check<T>(sc, S, qc, cnt, what, flags + off, cs, false, plan, gs, gstride, W.xcnt);
     GH_HIP(hipGetLastError());
   }
   for (int k = 0; k < n_sets && !fixed; k++) {

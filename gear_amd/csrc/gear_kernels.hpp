@@ -43,6 +43,7 @@ constexpr uint32_t kWhatNoLimits = 0x10u;
 #define GEAR_DBG(what, bits) false
 #endif
 constexpr unsigned kHitRedo = 0x80u;  // pipeline hit word, bit 7: re-check this configuration with the fused kernel
+constexpr unsigned kXRedo = 0xffffffffu;  // PipeWs::xcnt of a sweep wavefront whose exact region ran full: same request, per wavefront
 
 template <class T> struct Views {
   const GEAR_CAS NodeDev<T>* nodes;
@@ -320,31 +321,32 @@ constexpr size_t queue_bytes(int K) { return (size_t)(kQCap + kGCap + 4 + K * kW
 template <class T, bool COUNT, bool GSTORE, int K>
 __global__ void __launch_bounds__(kWave)
 k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t* __restrict__ flags,
-        CountersDev* __restrict__ ctr, T* gstore, size_t gstride, const unsigned* __restrict__ hit) {
+        CountersDev* __restrict__ ctr, T* gstore, size_t gstride, const unsigned* __restrict__ redo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   const Views<T> V(S);
   const int lane = threadIdx.x;
-  size_t i = (size_t)blockIdx.x * kWave + lane;
+  // redo == nullptr: the workgroup evaluates block blockIdx.x of 64 configurations.
+  // redo != nullptr: last stage of the pipeline (gear_pipeline.hpp), whose exact stage has written every flag byte:
+  // redo[b] == kXRedo marks a block whose sweep wavefront ran out of room and asks for this kernel's answer
+  // instead.  The workgroup looks at the marks of blocks 64 * blockIdx.x ... + 63 (one load) and evaluates the
+  // marked ones one after the other (normally none: the launch is a sixty-fourth of the blocks and returns).
+  const size_t n_blocks = (n + kWave - 1) / kWave;
+  const size_t base = redo ? (size_t)blockIdx.x * kWave : (size_t)blockIdx.x;
+  unsigned long long todo = 1;
+  if (redo) todo = __ballot(base + lane < n_blocks && redo[base + lane < n_blocks ? base + lane : 0] == kXRedo);
+  while (todo != 0) {
+  const size_t wb = base + (redo ? (size_t)__builtin_ctzll(todo) : (size_t)0);
+  todo &= todo - 1;
+  wave_sync<GSTORE>();  // (a second block reuses the first one's LDS)
+  size_t i = wb * kWave + lane;
   const bool live = i < n;
-  // hit != nullptr: last stage of the pipeline (gear_pipeline.hpp).  hit[i] already holds the flags
-  // of configuration i unless bit 7 asks for a re-check; a wave without such a lane only converts.
-  unsigned prior = 0;
-  bool need = true;
-  if (hit) {
-    prior = live ? hit[i] : 0u;
-    need = (prior & kHitRedo) != 0;
-    if (__ballot(need) == 0) {
-      if (live) flags[i] = (prior & 4u) ? (uint8_t)4 : (uint8_t)(prior & 3u);
-      return;
-    }
-  }
   if (!live) i = n - 1;  // keep the lane on valid data; it pushes and stores nothing
   const T* qrow = q + i * (size_t)S.n_cols;
   const int pose_slots = S.n_slots + S.n_shapes;
   WaveStore<T> st;
   unsigned* q1;
   if (GSTORE) {
-    st = {gstore, gstride, (size_t)blockIdx.x * kWave};
+    st = {gstore, gstride, wb * kWave};
     q1 = reinterpret_cast<unsigned*>(gear_lds);
   } else {
     st = {reinterpret_cast<T*>(gear_lds), (size_t)kWave, (size_t)0};
@@ -382,7 +384,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
   const int env_units = do_env ? (S.n_shapes + K - 1) / K * n_og : 0;
   const int self_groups = do_self ? (S.n_spairs + 31) / 32 : 0;
   const int units = env_units + self_groups;
-  const bool push_ok = live && ok && need;  // the reference evaluates no collision after a limit error
+  const bool push_ok = live && ok;  // the reference evaluates no collision after a limit error
   bool env_done = false, self_done = false;
   int qn = 0, gn = 0;  // wave-uniform queue fills
   int s0 = 0, o0 = 0;
@@ -542,10 +544,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
   wave_sync<GSTORE>();
   const bool env_hit = ((hits[lane >> 5] >> (lane & 31)) & 1u) != 0;
   const bool self_hit = ((hits[2 + (lane >> 5)] >> (lane & 31)) & 1u) != 0;
-  if (live) {
-    if (need) flags[i] = ok ? (uint8_t)((env_hit ? 1 : 0) | (self_hit ? 2 : 0)) : (uint8_t)4;
-    else flags[i] = (prior & 4u) ? (uint8_t)4 : (uint8_t)(prior & 3u);
-  }
+  if (live) flags[i] = ok ? (uint8_t)((env_hit ? 1 : 0) | (self_hit ? 2 : 0)) : (uint8_t)4;
   if (COUNT) {
     // counters live on whichever lane ran the test; only their sums are meaningful
     atomicAdd(&ctr->configs, live ? 1ull : 0ull);
@@ -555,6 +554,7 @@ k_check(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, uint8_t
     atomicAdd(&ctr->exact_tests, (unsigned long long)lc.exact_tests);
     atomicAdd(&ctr->exact_iters, (unsigned long long)lc.exact_iters);
   }
+  }  // while (todo)
 }
 
 // ---------------------------------------------------------------------------

@@ -61,7 +61,9 @@ template <class T> struct PipeWs {
   T* fq;            // [waves][n_first][64][4] rotation of every shape that is the earlier one of a self pair (same)
   PipeCounters* pc;
   unsigned capw;
-  unsigned* note;   // host word (as the device addresses it; may be null): set when a wavefront's exact region ran full
+  unsigned* note;
+  uint8_t* flags;   // the chunk's flag bytes (written by the exact stage, k_narrow2) and how many
+  unsigned n_cfg;   // host word (as the device addresses it; may be null): set when a wavefront's exact region ran full
 };
 
 // One ring / pose record = 8 T (32 B in f32, 64 B in f64), written and read with 16-byte accesses.
@@ -449,7 +451,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
     if (xover) out |= kHitRedo;
     if (xover && lane == 0 && wave_live && W.note) __hip_atomic_store(W.note, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (live) W.hit[wave * kWave + lane] = out;
-    if (lane == 0 && wave_live) W.xcnt[wave] = xover ? 0u : xcount;
+    if (lane == 0 && wave_live) W.xcnt[wave] = xover ? kXRedo : xcount;
   }
 }
 
@@ -480,12 +482,16 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned n_sweep_waves) {
   const unsigned nw = min((unsigned)kN2Tile, n_sweep_waves - w0);
   if (tid == 0) {
     unsigned acc = 0;
-    for (unsigned k = 0; k < nw; k++) { wpre[k] = acc; acc += min(W.xcnt[w0 + k], W.capw); }
+    for (unsigned k = 0; k < nw; k++) {
+      const unsigned x = W.xcnt[w0 + k];
+      wpre[k] = acc;
+      acc += x == kXRedo ? 0u : min(x, W.capw);  // a full region's wavefront is evaluated again by k_check
+    }
     for (unsigned k = nw; k <= (unsigned)kN2Tile; k++) wpre[k] = acc;
   }
   __syncthreads();
   const unsigned total = wpre[kN2Tile];
-  if (total == 0) return;  // uniform
+  if (total != 0) {  // uniform
   const Vec4Tab<T> lverts{reinterpret_cast<const Quad<T>*>(gear_lds)};
   const Vec4Tab<T> lplanes{reinterpret_cast<const Quad<T>*>(gear_lds) + S.n_verts};
   if (MLDS) {
@@ -571,6 +577,36 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned n_sweep_waves) {
       }
     }
     __syncthreads();  // sorted[] is reused by the next window
+  }
+  }
+  // Every hit of the tile's configurations is in (their entries all belong to this workgroup): hit word -> flag
+  // byte, eight configurations per thread: one pass for a tile of 32 wavefronts.  (Until round 3 a launch of its
+  // own did this: 21 us per 4M configurations, all of it workgroup dispatch.)  The words were updated by atomics of
+  // this workgroup's wavefronts (performed in the L2): each wavefront waits for its own before the barrier, and the
+  // loads behind it are device-scope atomic loads, which do not look at this compute unit's cached copies.  (A
+  // device-scope fence instead would write the L2 back per workgroup: measured, 3x the kernel.)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  const size_t c0 = (size_t)w0 * kWave;
+  const size_t c1 = min((size_t)(w0 + nw) * kWave, (size_t)W.n_cfg);
+  const bool wide = (reinterpret_cast<uintptr_t>(W.flags) & 7u) == 0;  // uniform; chunk offsets are multiples of 64
+  auto to_flag = [](unsigned h) -> unsigned { return (h & 4u) ? 4u : (h & 3u); };
+  for (size_t c = c0 + (size_t)tid * 8; c < c1; c += (size_t)kN2Threads * 8) {
+    if (c + 8 <= c1) {
+      unsigned h[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) h[k] = __hip_atomic_load(W.hit + c + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned lo = to_flag(h[0]) | (to_flag(h[1]) << 8) | (to_flag(h[2]) << 16) | (to_flag(h[3]) << 24);
+      const unsigned hi = to_flag(h[4]) | (to_flag(h[5]) << 8) | (to_flag(h[6]) << 16) | (to_flag(h[7]) << 24);
+      if (wide) {
+        *reinterpret_cast<uint2*>(W.flags + c) = make_uint2(lo, hi);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { W.flags[c + k] = (uint8_t)(lo >> (8 * k)); W.flags[c + 4 + k] = (uint8_t)(hi >> (8 * k)); }
+      }
+    } else {
+      for (size_t k = c; k < c1; k++) W.flags[k] = (uint8_t)to_flag(__hip_atomic_load(W.hit + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
   }
 }
 
