@@ -124,21 +124,32 @@ def _scene_with_env(w, prec, **env):
                 os.environ[k] = v
 
 
-def test_full_exact_regions_are_rechecked():
+@pytest.mark.parametrize("prec", [32, 64])
+def test_full_exact_regions_are_rechecked(prec):
     """GEAR_HIP_EXACT_CAP=2: a sweep wavefront may hand only two items to the exact stage, so nearly
     every wavefront overflows and its configurations are decided by the fused re-check inside the
-    pipeline's last stage.  The flags must not depend on that capacity."""
+    pipeline's last stage; with larger capacities only some wavefronts do (the last stage looks at 64 marks per
+    workgroup and evaluates the marked blocks one after the other).  The flags must not depend on that capacity."""
     for w in (W.metric_workload(), W.ur10_workload(128)):
-        hip = _scene_with_env(w, 32, GEAR_HIP_EXACT_CAP=2)
-        q = w.configs(100000, seed=35, overshoot=0.01)
-        got = hip.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
-        st = hip.pipeline_last_stats()
-        assert st["exact_cap"] == 2 and st["redo_waves"] > 100, st
-        ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
-        assert (got == ref.check_batch(q, BOTH | D.GH_PATH_FUSED)).all()
-        assert (got == ref.check_batch(q, BOTH)).all()
+        n = 100000 if prec == 32 else 40037
+        n_waves = (n + 63) // 64
+        ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+        q = w.configs(n, seed=35, dtype=ref.dtype, overshoot=0.01)
+        want = ref.check_batch(q, BOTH | D.GH_PATH_FUSED)
+        assert (want == ref.check_batch(q, BOTH)).all()
         ref.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
         assert ref.pipeline_last_stats()["redo_waves"] == 0           # the default capacity is not reached here
+        scattered = False
+        for cap in (2, 24, 48, 96):
+            hip = _scene_with_env(w, prec, GEAR_HIP_EXACT_CAP=cap)
+            got = hip.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
+            st = hip.pipeline_last_stats()
+            assert st["exact_cap"] == cap, st
+            if cap == 2:
+                assert st["redo_waves"] > n_waves // 16, st
+            scattered = scattered or 0 < st["redo_waves"] < n_waves // 2
+            assert (got == want).all(), (w.name, cap, st)
+        assert scattered, w.name
 
 
 def test_chunks_over_several_streams():

@@ -106,19 +106,25 @@ def test_in_place_host_calls_equal_copied_ones(prec):
 def test_flag_bytes_land_at_any_alignment_and_nowhere_else():
     """The exact stage writes the flag bytes (eight per store when the caller's array allows it): device arrays that
     start at every byte offset, ragged counts, and the bytes either side of the array stay as they were."""
-    import torch
+    import ctypes as C
+    from tests.test_zz_no_alloc import DeviceMem
     w = W.metric_workload()
     hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
     n = 70000 + 37
     q = w.configs(n, seed=29, dtype=hip.dtype, overshoot=0.01)
     want = hip.check_batch(q, BOTH | D.GH_PATH_FUSED)
-    qt = torch.from_numpy(q).cuda()
-    for shift in range(9):
-        for m in (n, 65536 + 5, 129):
-            buf = torch.full((n + 64,), 0xAB, dtype=torch.uint8, device="cuda")
-            out = buf[8 + shift: 8 + shift + m]
-            hip.check_batch_dev(qt[:m].contiguous(), out, BOTH | D.GH_PATH_PIPELINE)
-            torch.cuda.synchronize()
-            got = buf.cpu().numpy()
-            assert (got[8 + shift: 8 + shift + m] == want[:m]).all(), (shift, m)
-            assert (got[:8 + shift] == 0xAB).all() and (got[8 + shift + m:] == 0xAB).all(), (shift, m)
+    dq, buf = DeviceMem(q.nbytes), DeviceMem(n + 64)
+    dq.put(q)
+    try:
+        for shift in range(9):
+            for m in (n, 65536 + 5, 129):
+                buf.fill(0xAB, n + 64)
+                out = C.c_void_p(buf.p.value + 8 + shift)
+                rc = engine.lib().gh_check_batch_dev(hip.h, dq.p, m, BOTH | D.GH_PATH_PIPELINE, out, None)
+                assert rc == 0, engine.lib().gh_last_error()
+                got = buf.get(n + 64)
+                assert (got[8 + shift: 8 + shift + m] == want[:m]).all(), (shift, m)
+                assert (got[:8 + shift] == 0xAB).all() and (got[8 + shift + m:] == 0xAB).all(), (shift, m)
+    finally:
+        dq.free()
+        buf.free()
