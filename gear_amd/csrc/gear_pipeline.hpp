@@ -25,6 +25,8 @@ namespace gear_hip {
 
 constexpr int kClassBits = 4;  // pair classes of the exact stage (exact_class)
 constexpr int kClasses = 1 << kClassBits;
+// exact entry key, word x: class << 28 | kKeyLater | configuration within the chunk (chunks hold at most 2^27)
+constexpr unsigned kKeyLater = 1u << 27, kKeyCfg = kKeyLater - 1u;
 
 // Pair class of an undecided item: which support functions and which parts of the hollow-mesh rule its
 // exact query runs.  A wavefront of mixed items executes the union of all their paths, and with one or
@@ -183,7 +185,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   T* const first_base = reinterpret_cast<T*>(my_lds + slot_bytes);  // [n_first][3][64] centres
   T* const fq_wave = W.fq + wave * (size_t)S.n_first * kWave * 4;    // [n_first][64][4] rotations (memory)
   T* const ring = reinterpret_cast<T*>(my_lds + slot_bytes + first_bytes);  // [kRing][8]
-  unsigned* const hits = reinterpret_cast<unsigned*>(ring + (size_t)kRing * 8);  // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self
+  unsigned* const hits = reinterpret_cast<unsigned*>(ring + (size_t)kRing * 8);  // [0..1] env bits of lanes 0-31 / 32-63, [2..3] self, [4..7] "has an exact entry", likewise
   unsigned* const hlist = hits + 8;  // [kHitList] the hits of half a cell block: owner lane << 16 | obstacle
   // this lane's row of the batch
   QLds<T> qlds{reinterpret_cast<const T*>(hlist + kHitList) + lane};  // Q_LDS: [n_cols][64] behind the hit list
@@ -201,7 +203,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
       for (int k = threadIdx.x; k < (S.n_obs + 1) * 4; k += blockDim.x) tab[k] = S.ocull[k];
     }
     for (int k = threadIdx.x; k < S.n_shapes * 4; k += blockDim.x) rhot[k] = S.hot[k];
-    if (lane < 4) hits[lane] = 0;
+    if (lane < 8) hits[lane] = 0;
     __syncthreads();
   }
   const T* __restrict__ ohot = S.hot + (size_t)S.n_shapes * 4;  // obstacle part: 12 T per obstacle, gathered per item
@@ -283,8 +285,12 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
       if (xcount + tot > W.capw) {
         xover = true;  // the fused path re-checks this wavefront's configurations
       } else if (ex) {
+        // A configuration's FIRST entry of a kind is marked as such: the exact stage decides those first and looks
+        // at the others only where the first one did not hit (four of five entries hit on cylinder-rich scenes).
+        const unsigned obit = 1u << (ln & 31);
+        const unsigned later = (atomicOr(&hits[(sf ? 6 : 4) + (ln >> 5)], obit) & obit) ? kKeyLater : 0u;
         const size_t e = wave * (size_t)W.capw + xcount + lane_rank(eb);
-        W.xkey[e] = make_uint2((cls << 28) | (unsigned)(wave * kWave + (size_t)ln), code);
+        W.xkey[e] = make_uint2((cls << 28) | later | (unsigned)(wave * kWave + (size_t)ln), code);
         ItemIO<T>::store(W.xpose_a + e * 8, code, wa);
         if (sf) ItemIO<T>::store(W.xpose_b + e * 8, code, wb);
       }
@@ -466,16 +472,21 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
 // access per vertex or plane.
 // ---------------------------------------------------------------------------
 constexpr int kN2Threads = 256;
+#ifndef GEAR_N2_APART_MIN
+#define GEAR_N2_APART_MIN (kN2Threads / 2)  // later entries per window from which they wait for the first ones (64 ... 512 measure alike)
+#endif
 constexpr int kN2Window = 4096;  // entries binned at a time
 
 // kN2Tile: sweep wavefronts per workgroup (a power of two)
 template <class T, bool MLDS, bool HIST = false, int kN2Tile = 32>
-__global__ void __launch_bounds__(kN2Threads)
+__global__ void __launch_bounds__(kN2Threads, sweep_occupancy<T>())  // f32: four wavefronts per SIMD (the stage lives on latency hiding)
 k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned n_sweep_waves) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   __shared__ unsigned sorted[kN2Window];
   __shared__ unsigned wpre[kN2Tile + 1];  // prefix of the tile's entry counts
   __shared__ unsigned cbin[kClasses], cfill[kClasses], coff[kClasses + 1];
+  __shared__ unsigned cbin2[kClasses];  // the later entries' counts
+  __shared__ unsigned nlater[3];        // later entries of the window that wait: listed, still needed; do they wait at all
   const Views<T> V(S);
   const int tid = threadIdx.x;
   const unsigned w0 = blockIdx.x * (unsigned)kN2Tile;
@@ -512,43 +523,86 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned n_sweep_waves) {
   };
   for (unsigned k0 = 0; k0 < total; k0 += (unsigned)kN2Window) {
     const unsigned kend = min(total, k0 + (unsigned)kN2Window);
-    if (tid < kClasses) { cbin[tid] = 0; cfill[tid] = 0; }
+    if (tid < kClasses) { cbin[tid] = 0; cbin2[tid] = 0; cfill[tid] = 0; }
+    if (tid < 3) nlater[tid] = 0;
     __syncthreads();  // also: the mesh table is in
-    // (1) + (2a): which entries still matter, how many per class
+    // (1) + (2a): which entries still matter, how many per class — the configurations' first entries and the later
+    // ones counted apart
     for (unsigned k = k0 + (unsigned)tid; k < kend; k += kN2Threads) {
       const uint2 key = W.xkey[ebase + entry_of(k)];
       const unsigned bit = (key.y >> 31) ? 2u : 1u;
-      if ((W.hit[key.x & 0x0fffffffu] & (bit | kHitRedo)) == 0 && !GEAR_DBG(what, 0x100u)) atomicAdd(&cbin[key.x >> 28], 1u);
+      if ((W.hit[key.x & kKeyCfg] & (bit | kHitRedo)) == 0 && !GEAR_DBG(what, 0x100u))
+        atomicAdd((key.x & kKeyLater) ? &cbin2[key.x >> 28] : &cbin[key.x >> 28], 1u);
     }
     __syncthreads();
     if (tid == 0) {
+      // Later entries wait for the first ones' answers when there are enough of them to pay for a second round of
+      // queries (a round is one query per thread); otherwise everything is decided in one go, as before round 3.
+      // (Metric scene: a few later entries per window, one go.  6-DOF arm in a field of cylinders: 1.9 entries per
+      // configuration, five of six hit: the exact stage 287 -> 140 us per 1M, the call 2.05 -> 2.87 G configs/s.)
+      unsigned later = 0;
+      for (int c = 0; c < kClasses; c++) later += cbin2[c];
+      const bool apart = later >= (unsigned)GEAR_N2_APART_MIN;
       unsigned acc = 0;
-      for (int c = 0; c < kClasses; c++) { coff[c] = acc; acc += cbin[c]; }
+      for (int c = 0; c < kClasses; c++) { coff[c] = acc; acc += cbin[c] + (apart ? 0u : cbin2[c]); }
       coff[kClasses] = acc;
+      nlater[2] = apart ? 1u : 0u;
     }
     __syncthreads();
-    // (2b): place them
+    const bool apart = nlater[2] != 0;  // uniform
+    // (2b): place them: by class at the near end of sorted[]; later entries that wait, from the far end (every entry
+    // of the window goes to one list or the other)
     for (unsigned k = k0 + (unsigned)tid; k < kend; k += kN2Threads) {
       const unsigned eo = entry_of(k);
       const uint2 key = W.xkey[ebase + eo];
       const unsigned bit = (key.y >> 31) ? 2u : 1u;
-      if ((W.hit[key.x & 0x0fffffffu] & (bit | kHitRedo)) == 0 && !GEAR_DBG(what, 0x100u)) {
-        const unsigned c = key.x >> 28;
-        sorted[coff[c] + atomicAdd(&cfill[c], 1u)] = eo;
+      if ((W.hit[key.x & kKeyCfg] & (bit | kHitRedo)) == 0 && !GEAR_DBG(what, 0x100u)) {
+        if (apart && (key.x & kKeyLater)) {
+          sorted[kN2Window - 1 - atomicAdd(&nlater[0], 1u)] = eo;
+        } else {
+          const unsigned c = key.x >> 28;
+          sorted[coff[c] + atomicAdd(&cfill[c], 1u)] = eo;
+        }
       }
     }
     __syncthreads();
-    // (3): groups of 64 sorted entries, round robin over the wavefronts
-    const unsigned kept = coff[kClasses];
+    // (3): groups of 64 listed entries, round robin over the wavefronts — the first entries, then what is left of the
+    // later ones
+    for (int phase = 0; phase < 2; phase++) {
+      unsigned kept = coff[kClasses];
+      bool back = false;  // the list runs down from the far end of sorted[]
+      if (phase == 1) {
+        const unsigned n_later = nlater[0];
+        if (n_later == 0) break;  // uniform
+        // the first entries' hits (device-scope atomics of this workgroup's wavefronts) decide which later entries
+        // are still needed: each wavefront waits for its own atomics, barrier, device-scope atomic loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (n_later <= (unsigned)kN2Window / 2) {  // made dense at the near end (the two regions cannot meet)
+          for (unsigned j = (unsigned)tid; j < n_later; j += kN2Threads) {
+            const unsigned eo = sorted[kN2Window - 1 - j];
+            const uint2 key = W.xkey[ebase + eo];
+            const unsigned bit = (key.y >> 31) ? 2u : 1u;
+            const unsigned h = __hip_atomic_load(W.hit + (key.x & kKeyCfg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((h & bit) == 0) sorted[atomicAdd(&nlater[1], 1u)] = eo;
+          }
+          __syncthreads();
+          kept = nlater[1];
+        } else {  // (a window of mostly later entries: taken where they lie, each lane looking at its hit word)
+          kept = n_later;
+          back = true;
+        }
+      }
     for (unsigned g = (unsigned)(tid >> 6) * kWave; g < kept; g += kN2Threads) {
       const unsigned j = g + (unsigned)(tid & 63);
       if (j >= kept) continue;
-      size_t e = ebase + sorted[j];
+      size_t e = ebase + sorted[back ? kN2Window - 1 - j : j];
       if (GEAR_DBG(what, 0x400000u)) e = ebase + sorted[g];  // profiling ablation: one item per wave, no divergence
       const uint2 key = W.xkey[e];
       const unsigned code = key.y;
-      const size_t cfg = key.x & 0x0fffffffu;
+      const size_t cfg = key.x & kKeyCfg;
       const bool sf = (code >> 31) != 0;
+      if (back && (__hip_atomic_load(W.hit + cfg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (sf ? 2u : 1u))) continue;
       ShapeRef<T> A, B;
       Pose<T> wb;
       const Pose<T> wa = ItemIO<T>::pose(W.xpose_a + e * 8);
@@ -576,6 +630,7 @@ k_narrow2(SceneDev<T> S, uint32_t what, PipeWs<T> W, unsigned n_sweep_waves) {
         lc.exact_iters = 0;
       }
     }
+    }  // phase
     __syncthreads();  // sorted[] is reused by the next window
   }
   }
