@@ -287,7 +287,10 @@ inline void build_grids(HostTables<T>& H, double margin) {
   const char* e_cls = getenv("GEAR_HIP_GRID_CLASSES");  // tuning aids
   const char* e_h = getenv("GEAR_HIP_GRID_H");
   const size_t max_cls = e_cls ? (size_t)std::max(1, atoi(e_cls)) : 4;
-  const double h_scale = e_h ? std::max(0.05, atof(e_h)) : 1.0;
+  // cell edge = half of max(extent / 48, half the median reach, 0.02): cells a quarter of the median reach list ~2.5
+  // candidates per shape instead of 3.7 and make the sweep 2-8 % faster on five scenes (finer: nothing more; the
+  // cell blocks then leave the L2)
+  const double h_scale = e_h ? std::max(0.05, atof(e_h)) : 0.5;
   const int n_cls = (int)std::min<size_t>(max_cls, sorted.size());
   std::vector<double> cls_r(n_cls);
   for (int c = 0; c < n_cls; c++) cls_r[c] = sorted[(size_t)((c + 1) * sorted.size() / n_cls) - 1];
