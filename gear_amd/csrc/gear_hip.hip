@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -116,6 +117,7 @@ struct Knobs {
   size_t pipe_chunk = size_t(4) << 20;  // GEAR_HIP_PIPE_CHUNK: configurations per pipeline pass (at most; a call's chunks are equal)
   int pipe_streams = kMaxSets;          // GEAR_HIP_PIPE_STREAMS: 1 keeps every chunk on the caller's stream
   size_t exact_cap = 0;                 // GEAR_HIP_EXACT_CAP: exact entries per sweep wavefront, fixed (tests force re-checks with it)
+  int fail_part = -1;                   // GEAR_HIP_TEST_FAIL_PART: this share of a device group's call reports a failure (tests)
   size_t exact_cap0 = 0;                // GEAR_HIP_EXACT_CAP0: ... to start with; grows as usual when regions run full (tests)
   bool zero_copy = true;                // GEAR_HIP_ZERO_COPY=0: host-buffer calls always copy (measuring aid)
   bool sweep_clds = true;               // GEAR_HIP_SWEEP_CLDS=0: cull table never in LDS
@@ -137,6 +139,7 @@ struct Knobs {
     k.pipe_streams = (int)(x < 1 ? 1 : x > kMaxSets ? kMaxSets : x);
     k.exact_cap = (size_t)std::max<long long>(0, num("GEAR_HIP_EXACT_CAP", 0));
     k.exact_cap0 = (size_t)std::max<long long>(0, num("GEAR_HIP_EXACT_CAP0", 0));
+    k.fail_part = (int)num("GEAR_HIP_TEST_FAIL_PART", -1);
     k.zero_copy = num("GEAR_HIP_ZERO_COPY", 1) != 0;
     k.sweep_clds = num("GEAR_HIP_SWEEP_CLDS", 1) != 0;
     k.sweep_waves = (int)num("GEAR_HIP_SWEEP_WAVES", 0);
@@ -787,6 +790,7 @@ int run_parts(gh_scene* sc, size_t n_parts, F&& body) {  // body(k) -> status; e
   std::vector<std::thread> pool;
   auto guarded = [&](size_t k) {  // nothing may throw across the extern "C" boundary (nor out of a thread)
     try {
+      if (sc->knobs.fail_part == (int)k) throw std::runtime_error("share " + std::to_string(k) + " was told to fail (GEAR_HIP_TEST_FAIL_PART)");
       rc[k] = body(k);
       if (rc[k]) msg[k] = g_last_error;
     } catch (const std::exception& e) {
@@ -1024,6 +1028,7 @@ int gh_scene_create_multi(const gh_robot_desc* robot, const gh_obstacle_desc* ob
   const gh_scene* p0 = grp->parts[0];
   grp->precision = p0->precision; grp->device = p0->device; grp->margin = p0->margin;
   grp->D = p0->D; grp->N = p0->N; grp->L = p0->L; grp->O = p0->O; grp->O_user = p0->O_user; grp->P = p0->P;
+  grp->knobs = p0->knobs;
   *out = grp;
   return GH_OK;
 }

@@ -50,3 +50,31 @@ def test_group_rejects_device_pointer_calls_and_bad_lists():
         engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32, devices=[0, 99])
     with pytest.raises(engine.GearHipError):
         engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32, devices=[])
+
+
+def test_a_failing_share_is_reported_and_nothing_hangs():
+    """One share of a group call fails (a test hook makes share 1 throw): the call returns that share's error with its
+    device named, the other shares have finished (no thread is left behind, the call returns), and the group, a second
+    group and a plain scene all work afterwards — the per-device pools and locks were released."""
+    import os
+    w = W.metric_workload(64)
+    q = w.configs(300000, seed=12, overshoot=0.01)          # large enough to be cut into shares
+    one = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32)
+    want = one.check_batch(q, BOTH)
+    os.environ["GEAR_HIP_TEST_FAIL_PART"] = "1"
+    try:
+        bad = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32, devices=[0, 0, 0])
+    finally:
+        del os.environ["GEAR_HIP_TEST_FAIL_PART"]
+    for _ in range(3):
+        with pytest.raises(engine.GearHipError) as e:
+            bad.check_batch(q, BOTH)
+        assert "device 0" in str(e.value) and "told to fail" in str(e.value)
+    off = np.arange(0, 300001, 50, dtype=np.uint32)
+    with pytest.raises(engine.GearHipError):
+        bad.check_edges(q, off)
+    # a call small enough for one device's share never reaches share 1
+    assert (bad.check_batch(q[:1000], BOTH) == want[:1000]).all()
+    good = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, 32, devices=[0, 0, 0])
+    assert (good.check_batch(q, BOTH) == want).all()
+    assert (one.check_batch(q, BOTH) == want).all()
