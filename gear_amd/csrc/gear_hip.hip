@@ -440,7 +440,7 @@ SweepPlan plan_sweep(const gh_scene* sc, const SceneDev<T>& S, bool do_env, bool
   const size_t q_bytes = (size_t)S.n_cols * kWave * sizeof(T);
   const size_t base_wave = slot_bytes + first_bytes + (size_t)kRing * 8 * sizeof(T) + 32 + (size_t)kHitList * 4;
   const size_t rhot = ((size_t)S.n_shapes * 4 * sizeof(T) + 15) / 16 * 16;
-  const size_t table = ((size_t)(S.n_obs + 1) * 4 * sizeof(T) + 15) / 16 * 16;
+  const size_t table = (size_t)(S.n_obs + 1) * 4 * sizeof(float);  // in LDS the cull table is f32 in both precisions (k_sweep_n1)
   const size_t reg_waves = sizeof(T) == 4 ? 16 : 8;  // wavefronts per CU the registers allow (128 / 215 VGPRs)
   // The cull table in LDS takes the cell blocks' record fetches (and the re-reads of the per-hit passes) off
   // the texture-address path, which is what this kernel otherwise queues on: it wins even where it costs a

@@ -19,6 +19,8 @@
 // is_feasible_with_self (src/planner/joint_path_planner.rs:71-84,113-121); only the order in which pairs
 // are looked at differs, and the flags are an OR over pairs.
 #pragma once
+#include <type_traits>
+
 #include "gear_kernels.hpp"
 
 namespace gear_hip {
@@ -165,6 +167,13 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
            unsigned per_wave_lds, unsigned first_bytes, int all_blk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gear_lds[];
   using Rec = typename ItemIO<T>::Rec;
+  // The two culls are conservative filters in front of an exact decision: their table is inflated by 1e-4 of the
+  // radii, the cell lists by 1e-5 m and more, the oriented box by 1e-5.  With the table in LDS they are evaluated in
+  // f32 in BOTH precisions (the f64 kernel's vector unit runs f64 at half the rate, its table took twice the LDS):
+  // a double rounded to float moves by 6e-8 of its size, far inside those paddings, so the survivors still include
+  // every pair within the margin and the flags stay the brute-force sweep's.
+  using C = typename std::conditional<CLDS, float, T>::type;
+  constexpr bool kSameC = std::is_same<C, T>::value;
   const Views<T> V(S);
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
@@ -199,8 +208,8 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   };
   {
     if (CLDS) {
-      T* tab = reinterpret_cast<T*>(gear_lds);
-      for (int k = threadIdx.x; k < (S.n_obs + 1) * 4; k += blockDim.x) tab[k] = S.ocull[k];
+      C* tab = reinterpret_cast<C*>(gear_lds);
+      for (int k = threadIdx.x; k < (S.n_obs + 1) * 4; k += blockDim.x) tab[k] = (C)S.ocull[k];
     }
     for (int k = threadIdx.x; k < S.n_shapes * 4; k += blockDim.x) rhot[k] = S.hot[k];
     if (lane < 8) hits[lane] = 0;
@@ -214,7 +223,7 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
   const GEAR_CAS GridDev<T>* grids = to_cas(S.grids);
   const GEAR_CAS int32_t* shape_grid = to_cas(S.shape_grid);
   const uint4* __restrict__ blocks = reinterpret_cast<const uint4*>(S.cell_blk);
-  const Cull4<T>* __restrict__ ocull = CLDS ? reinterpret_cast<const Cull4<T>*>(gear_lds) : reinterpret_cast<const Cull4<T>*>(S.ocull);
+  const Cull4<C>* __restrict__ ocull = CLDS ? reinterpret_cast<const Cull4<C>*>(gear_lds) : reinterpret_cast<const Cull4<C>*>(S.ocull);
   const unsigned sentinel = (unsigned)S.n_obs;
 
   const bool ok = (what & kWhatNoLimits) != 0 || limits_ok(S, V, qrow());  // GH_CHECK_NO_LIMITS: geometry only
@@ -347,32 +356,34 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
       blk = (push_ok && !env_done) ? (unsigned)all_blk : 0u;  // GH_PATH_NO_GRID: the chain that lists every obstacle
     } else {
       const GEAR_CAS GridDev<T>* g = grids + shape_grid[s];
-      const T fx = (ws.t.x - g->org[0]) * g->inv_h, fy = (ws.t.y - g->org[1]) * g->inv_h, fz = (ws.t.z - g->org[2]) * g->inv_h;
-      const bool inside = push_ok && !env_done && fx >= T(0) && fy >= T(0) && fz >= T(0) && fx < T(g->nx) && fy < T(g->ny) && fz < T(g->nz);
+      const C fx = ((C)ws.t.x - (C)g->org[0]) * (C)g->inv_h, fy = ((C)ws.t.y - (C)g->org[1]) * (C)g->inv_h,
+              fz = ((C)ws.t.z - (C)g->org[2]) * (C)g->inv_h;
+      const bool inside = push_ok && !env_done && fx >= C(0) && fy >= C(0) && fz >= C(0) && fx < C(g->nx) && fy < C(g->ny) && fz < C(g->nz);
       if (inside) blk = (unsigned)g->off_base + ((unsigned)(int)fz * (unsigned)g->ny + (unsigned)(int)fy) * (unsigned)g->nx + (unsigned)(int)fx;
     }
     if (__ballot(blk != 0) == 0) continue;  // no lane of the wavefront has a list to look at
-    const T rho = sh->br;
+    const C rho = (C)sh->br;
     // the shape's oriented box: half extents padded by the rounding of the transformed offset (a ball: the
     // cube around it).  The offset is rotated with the pose quaternion itself: a rotation matrix would be
     // nine more registers live across the drain below.
     const bool is_ball = sh->kind == SK_BALL;
-    const T pad = T(1e-5) * (T(1) + rho);
-    const T hbx = sh->half[0] + pad, hby = (is_ball ? sh->half[0] : sh->half[1]) + pad, hbz = (is_ball ? sh->half[0] : sh->half[2]) + pad;
+    const C pad = C(1e-5) * (C(1) + rho);
+    const C hbx = (C)sh->half[0] + pad, hby = (C)(is_ball ? sh->half[0] : sh->half[1]) + pad, hbz = (C)(is_ball ? sh->half[0] : sh->half[2]) + pad;
+    const Pose<C> wc{{(C)ws.t.x, (C)ws.t.y, (C)ws.t.z}, {(C)ws.r.i, (C)ws.r.j, (C)ws.r.k, (C)ws.r.w}};  // the shape's pose as the culls see it
     bool more;
     do {
       const uint4 w = blocks[blk];
       const bool cont = (w.w >> 31) != 0;
       unsigned id[8] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, w.z >> 16, w.w & 0xffffu, w.w >> 16};
       if (cont) id[6] = id[7] = sentinel;
-      Cull4<T> oc[8];
+      Cull4<C> oc[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) oc[j] = ocull[id[j]];  // eight independent loads; a sentinel reads the far dummy
       unsigned h = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const T dx = ws.t.x - oc[j].x, dy = ws.t.y - oc[j].y, dz = ws.t.z - oc[j].z;
-        const T rr = rho + oc[j].r;
+        const C dx = wc.t.x - oc[j].x, dy = wc.t.y - oc[j].y, dz = wc.t.z - oc[j].z;
+        const C rr = rho + oc[j].r;
         h |= (dx * dx + dy * dy + dz * dz < rr * rr) ? (1u << j) : 0u;
       }
       if (what & 0x8000u) {  // diagnostic count of the candidates (wave-uniform: no register per lane)
@@ -405,17 +416,27 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
           unsigned e = hlist[have ? p0 + (unsigned)lane : 0u];
           int src = (int)(e >> 16);
           unsigned idz = have ? (e & 0xffffu) : sentinel;
-          Pose<T> sp{{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
-                     {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
+          // the owner's pose: as the cull sees it (f32 in both precisions when the table is in LDS) and, for the
+          // record, exact
+          Pose<T> sp;
+          Pose<C> sc;
+          if constexpr (kSameC) {
+            sp = {{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
+                  {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
+            sc = sp;
+          } else {
+            sc = {{__shfl(wc.t.x, src), __shfl(wc.t.y, src), __shfl(wc.t.z, src)},
+                  {__shfl(wc.r.i, src), __shfl(wc.r.j, src), __shfl(wc.r.k, src), __shfl(wc.r.w, src)}};
+          }
           bool pass = have;
           if (!GEAR_DBG(what, 0x200000u)) {
-            const Cull4<T> c = ocull[idz];
-            const T dx = c.x - sp.t.x, dy = c.y - sp.t.y, dz = c.z - sp.t.z;
+            const Cull4<C> c = ocull[idz];
+            const C dx = c.x - sc.t.x, dy = c.y - sc.t.y, dz = c.z - sc.t.z;
             // R^T d = d + w t' + u x t' with u = -(i, j, k), t' = 2 u x d
-            const T ui = -sp.r.i, uj = -sp.r.j, uk = -sp.r.k;
-            const T tx = T(2) * (uj * dz - uk * dy), ty = T(2) * (uk * dx - ui * dz), tz = T(2) * (ui * dy - uj * dx);
-            const T px = dx + sp.r.w * tx + (uj * tz - uk * ty), py = dy + sp.r.w * ty + (uk * tx - ui * tz), pz = dz + sp.r.w * tz + (ui * ty - uj * tx);
-            const T ex = t_max(t_abs(px) - hbx, T(0)), ey = t_max(t_abs(py) - hby, T(0)), ez = t_max(t_abs(pz) - hbz, T(0));
+            const C ui = -sc.r.i, uj = -sc.r.j, uk = -sc.r.k;
+            const C tx = C(2) * (uj * dz - uk * dy), ty = C(2) * (uk * dx - ui * dz), tz = C(2) * (ui * dy - uj * dx);
+            const C px = dx + sc.r.w * tx + (uj * tz - uk * ty), py = dy + sc.r.w * ty + (uk * tx - ui * tz), pz = dz + sc.r.w * tz + (ui * ty - uj * tx);
+            const C ex = t_max(t_abs(px) - hbx, C(0)), ey = t_max(t_abs(py) - hby, C(0)), ez = t_max(t_abs(pz) - hbz, C(0));
             pass = have && (ex * ex + ey * ey + ez * ez < c.r * c.r);
           }
           if (__ballot(pass) == 0) continue;
@@ -426,10 +447,14 @@ k_sweep_n1(SceneDev<T> S, const T* __restrict__ q, size_t n, uint32_t what, Pipe
             e = hlist[have ? p0 + (unsigned)lane : 0u];
             src = (int)(e >> 16);
             idz = have ? (e & 0xffffu) : sentinel;
-            sp = {{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
-                  {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
+            if constexpr (kSameC)
+              sp = {{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
+                    {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
             pass = pass && ((hits[src >> 5] >> (src & 31)) & 1u) == 0;  // the owner was decided meanwhile
           }
+          if constexpr (!kSameC)
+            sp = {{__shfl(ws.t.x, src), __shfl(ws.t.y, src), __shfl(ws.t.z, src)},
+                  {__shfl(ws.r.i, src), __shfl(ws.r.j, src), __shfl(ws.r.k, src), __shfl(ws.r.w, src)}};
           const unsigned long long pb = __ballot(pass);
           if (pass) ItemIO<T>::store(ring + (size_t)((head + count + lane_rank(pb)) & (unsigned)(kRing - 1)) * 8,
                                      (idz << 16) | ((unsigned)s << 6) | (unsigned)src, sp);
