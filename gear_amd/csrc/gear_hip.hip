@@ -499,7 +499,7 @@ int pipeline_dev(gh_scene* sc, const SceneDev<T>& S, const T* q, size_t n, uint3
   const size_t max_waves = std::max<size_t>((size_t(3) << 30) / (entry_bytes * capw), 64);
   const size_t n_pad = (n + kWave - 1) / kWave * kWave;
   const size_t chunk_max = std::min({n_pad, sc->knobs.pipe_chunk, max_waves * kWave, (size_t)1 << 27});
-  // the fused kernel is the last stage (flag conversion + re-checks): it needs its own pose columns
+  // the fused kernel is the last stage (re-checks of full exact regions): it needs its own pose columns
   StorePlan plan = plan_store(sc, true);
   // Consecutive chunks are independent.  With several workspace sets they rotate over the caller's
   // stream and the aux streams (fork / join through events), so that one chunk's exact stage, which

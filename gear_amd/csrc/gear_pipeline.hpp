@@ -11,9 +11,10 @@
 //               or two boxes are closer than the margin on their best axis) with their poses.
 //   k_narrow2   the exact stage over those items: drops the ones whose configuration is already known
 //               to collide, bins the rest by pair class in LDS so that the lanes of a wavefront take the
-//               same branches, then GJK margin query + hollow-mesh rule, one item per lane.
-//   k_check<hit>  hit word -> flag byte; a wavefront whose exact region ran full is re-checked by the fused
-//               path in the same launch, so the result never depends on a capacity.
+//               same branches, then GJK margin query + hollow-mesh rule, one item per lane — a configuration's
+//               first item first, the later ones only where that did not hit — and writes the flag bytes.
+//   k_check<redo>  a sweep wavefront whose exact region ran full is re-checked by the fused path (a workgroup
+//               looks at 64 marks and normally finds none), so the result never depends on a capacity.
 //
 // Reference semantics are unchanged: per configuration this evaluates is_feasible /
 // is_feasible_with_self (src/planner/joint_path_planner.rs:71-84,113-121); only the order in which pairs
