@@ -232,10 +232,10 @@ def main():
             os.environ.setdefault(k, v)               # plain `python bench.py --force-collectives`: a one-rank group
         dist.init_process_group("nccl", device_id=device)
         # the scene would rotate a call's chunks over the caller's stream and three of its own; the box gives a
-        # process four hardware queues and RCCL's stream needs one for the flag gather.  One stream (two chunks of
-        # 4M one after the other) measures the same as four on this scene and more than three (4.48 / 4.47 / 4.40
-        # G configs/s at N=1, profiles/r02/chunking.txt), so the sharded run keeps the step on the caller's stream.
-        os.environ.setdefault("GEAR_HIP_PIPE_STREAMS", "1")
+        # process four hardware queues and RCCL's stream needs one for the flag gather.  Measured on the one-rank
+        # group with the round-3 kernels (profiles/r03/rccl_path_n1.json): two streams 4.77 G configs/s, three 4.70,
+        # four 4.63, one 4.56 — so the sharded run rotates its chunks over the caller's stream and one more.
+        os.environ.setdefault("GEAR_HIP_PIPE_STREAMS", "2")
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
