@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace gear_hip {
 
 constexpr uint32_t kEdgeConnect = 0u, kEdgeWalk = 1u;
@@ -31,16 +33,29 @@ constexpr int kEdgeMaxDof = 64;                   // a lane keeps its walker in 
 
 #pragma clang fp contract(off)
 template <class T> __device__ __forceinline__ T edge_sqrt(T x);
-template <> __device__ __forceinline__ float edge_sqrt<float>(float x) { return __fsqrt_rn(x); }
-template <> __device__ __forceinline__ double edge_sqrt<double>(double x) { return __dsqrt_rn(x); }
+// the IEEE square root (llvm.sqrt without approximation flags; hipcc rounds f32 division and square root correctly by
+// default).  NOT __fsqrt_rn: in this toolchain's headers that is the NATIVE square root unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined, and whether it comes out refined depended on the instantiation.
+template <> __device__ __forceinline__ float edge_sqrt<float>(float x) { return __builtin_sqrtf(x); }
+template <> __device__ __forceinline__ double edge_sqrt<double>(double x) { return __builtin_sqrt(x); }
 
 // One edge's recurrence.  emit(j, cur) is called with sample j's coordinates (cur[0..D)); returns the number of
 // samples, with kEdgeTruncated OR-ed in when max_len ended the edge.
-template <class T, class Emit>
-__device__ __forceinline__ uint32_t edge_walk(const T* __restrict__ from, const T* __restrict__ to, int D, T step,
+// DD > 0: the number of columns is DD, known to the compiler — walker and target live in registers and the loops
+// unroll (same operations in the same order: same bits).  DD == 0: any D up to kEdgeMaxDof, the walker in scratch
+// memory (a serial chain of ~120 steps per edge through scratch took 4 us a step: 1.07 ms of a 3.5 ms call for the
+// 6-DOF scene's 65536 edges before the columns became a template argument).
+template <class T, int DD, class Emit>
+__device__ __forceinline__ uint32_t edge_walk(const T* __restrict__ from, const T* __restrict__ to_mem, int D_rt, T step,
                                               uint32_t max_len, uint32_t mode, Emit&& emit) {
-  T cur[kEdgeMaxDof];
+  constexpr int N = DD > 0 ? DD : kEdgeMaxDof;
+  const int D = DD > 0 ? DD : D_rt;
+  T cur[N];
+  T to_reg[DD > 0 ? DD : 1];
   for (int i = 0; i < D; i++) cur[i] = from[i];
+  if (DD > 0)
+    for (int i = 0; i < D; i++) to_reg[i] = to_mem[i];
+  const T* to = DD > 0 ? to_reg : to_mem;
   uint32_t n = 0;
   for (;;) {
     T s = T(0);
@@ -67,13 +82,13 @@ __device__ __forceinline__ uint32_t edge_walk(const T* __restrict__ from, const 
 #pragma clang fp contract(fast)
 
 // pass 1: samples per edge
-template <class T>
+template <class T, int DD>
 __global__ void __launch_bounds__(256)
 k_edge_count(const T* __restrict__ from, const T* __restrict__ to, size_t n_edges, int D, T step, uint32_t max_len,
              uint32_t mode, uint32_t* __restrict__ cnt) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n_edges) return;
-  cnt[e] = edge_walk<T>(from + e * (size_t)D, to + e * (size_t)D, D, step, max_len, mode, [](uint32_t, const T*) {});
+  cnt[e] = edge_walk<T, DD>(from + e * (size_t)D, to + e * (size_t)D, D, step, max_len, mode, [](uint32_t, const T*) {});
 }
 
 // exclusive prefix sum of cnt (bit 31 masked off) into off[0..n_edges], three small launches:
@@ -126,17 +141,33 @@ k_edge_scan3(uint32_t* __restrict__ off, size_t n_edges, const uint32_t* __restr
 }
 
 // pass 2: the samples themselves, row-major at off[e]
-template <class T>
+template <class T, int DD>
 __global__ void __launch_bounds__(256)
 k_edge_fill(const T* __restrict__ from, const T* __restrict__ to, size_t n_edges, int D, T step, uint32_t max_len,
             uint32_t mode, const uint32_t* __restrict__ off, T* __restrict__ q) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n_edges) return;
-  T* out = q + (size_t)off[e] * (size_t)D;
-  edge_walk<T>(from + e * (size_t)D, to + e * (size_t)D, D, step, max_len, mode, [&](uint32_t j, const T* cur) {
-    T* row = out + (size_t)j * (size_t)D;
-    for (int i = 0; i < D; i++) row[i] = cur[i];
+  const int Dn = DD > 0 ? DD : D;  // (a bound the compiler knows keeps the walker in registers)
+  T* out = q + (size_t)off[e] * (size_t)Dn;
+  edge_walk<T, DD>(from + e * (size_t)Dn, to + e * (size_t)Dn, D, step, max_len, mode, [&](uint32_t j, const T* cur) {
+    T* row = out + (size_t)j * (size_t)Dn;
+    for (int i = 0; i < Dn; i++) row[i] = cur[i];
   });
+}
+
+// f(std::integral_constant<int, D>) for D = 1..8, f(integral_constant<int, 0>) (any D, at run time) beyond
+template <class F> inline void by_columns(int D, F&& f) {
+  switch (D) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 5: f(std::integral_constant<int, 5>{}); break;
+    case 6: f(std::integral_constant<int, 6>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    default: f(std::integral_constant<int, 0>{}); break;
+  }
 }
 
 }  // namespace gear_hip

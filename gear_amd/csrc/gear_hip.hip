@@ -1368,12 +1368,17 @@ static int edges_count_scan(gh_scene* sc, const void* from_dev, const void* to_d
   int rc = sc->ebsum.ensure((n_blocks + 1) * 4);
   if (rc) return rc;
   const dim3 g256((unsigned)((n_edges + 255) / 256));
-  if (sc->precision == 32)
-    hipLaunchKernelGGL((k_edge_count<float>), g256, dim3(256), 0, st, (const float*)from_dev, (const float*)to_dev, n_edges, sc->D,
-                       (float)step, max_len, mode, cnt_dev);
-  else
-    hipLaunchKernelGGL((k_edge_count<double>), g256, dim3(256), 0, st, (const double*)from_dev, (const double*)to_dev, n_edges, sc->D,
-                       step, max_len, mode, cnt_dev);
+  // (the number of columns as a template argument up to 8: the walker stays in registers)
+  auto go = [&](auto dd) {
+    constexpr int DD = decltype(dd)::value;
+    if (sc->precision == 32)
+      hipLaunchKernelGGL((k_edge_count<float, DD>), g256, dim3(256), 0, st, (const float*)from_dev, (const float*)to_dev, n_edges, sc->D,
+                         (float)step, max_len, mode, cnt_dev);
+    else
+      hipLaunchKernelGGL((k_edge_count<double, DD>), g256, dim3(256), 0, st, (const double*)from_dev, (const double*)to_dev, n_edges, sc->D,
+                         step, max_len, mode, cnt_dev);
+  };
+  by_columns(sc->D, go);
   hipLaunchKernelGGL(k_edge_scan1, dim3((unsigned)n_blocks), dim3(1024), 0, st, cnt_dev, n_edges, off_dev, (uint32_t*)sc->ebsum.p);
   hipLaunchKernelGGL(k_edge_scan2, dim3(1), dim3(1024), 0, st, (uint32_t*)sc->ebsum.p, n_blocks);
   hipLaunchKernelGGL(k_edge_scan3, dim3((unsigned)n_blocks), dim3(1024), 0, st, off_dev, n_edges, (const uint32_t*)sc->ebsum.p, n_blocks);
@@ -1384,12 +1389,16 @@ static int edges_count_scan(gh_scene* sc, const void* from_dev, const void* to_d
 static void edges_fill(gh_scene* sc, const void* from_dev, const void* to_dev, size_t n_edges, double step, uint32_t max_len,
                        uint32_t mode, const uint32_t* off_dev, void* q_dev, hipStream_t st) {
   const dim3 g256((unsigned)((n_edges + 255) / 256));
-  if (sc->precision == 32)
-    hipLaunchKernelGGL((k_edge_fill<float>), g256, dim3(256), 0, st, (const float*)from_dev, (const float*)to_dev, n_edges, sc->D,
-                       (float)step, max_len, mode, off_dev, (float*)q_dev);
-  else
-    hipLaunchKernelGGL((k_edge_fill<double>), g256, dim3(256), 0, st, (const double*)from_dev, (const double*)to_dev, n_edges, sc->D,
-                       step, max_len, mode, off_dev, (double*)q_dev);
+  auto go = [&](auto dd) {
+    constexpr int DD = decltype(dd)::value;
+    if (sc->precision == 32)
+      hipLaunchKernelGGL((k_edge_fill<float, DD>), g256, dim3(256), 0, st, (const float*)from_dev, (const float*)to_dev, n_edges, sc->D,
+                         (float)step, max_len, mode, off_dev, (float*)q_dev);
+    else
+      hipLaunchKernelGGL((k_edge_fill<double, DD>), g256, dim3(256), 0, st, (const double*)from_dev, (const double*)to_dev, n_edges, sc->D,
+                         step, max_len, mode, off_dev, (double*)q_dev);
+  };
+  by_columns(sc->D, go);
 }
 
 static int edges_args_ok(const gh_scene* sc, double step, uint32_t max_len, uint32_t mode) {

@@ -124,3 +124,30 @@ def test_planner_bulk_validation_from_endpoints(tmp_path):
     o = off.astype(np.int64)
     want = np.array([next((j - o[e] for j in range(o[e], o[e + 1]) if not ok[j]), -1) for e in range(5000)])
     assert (first == want).all()
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_every_column_count_steps_alike(prec):
+    """The walker is compiled per column count up to 8 (registers) and once for any count beyond (scratch memory):
+    7 columns (the metric arm) and 15 (the dual-arm robot) must give the host stepping's bits like the 6 above."""
+    for w in (W.metric_workload(64), W.pr2_workload(32)):
+        hip = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+        E = 3000
+        a, b = _ends(w, E, hip.dtype, seed=71)
+        for mode in (D.GH_EDGE_CONNECT, D.GH_EDGE_WALK):
+            q_ref, off_ref = W.edge_samples_lockstep(a, b, 0.1, mode)
+            n = int(off_ref[-1])
+            first, cnt = hip.check_edges_from_endpoints(a, b, 0.1, 4096, mode, D.GH_CHECK_ENV, BAD)
+            assert (cnt == (off_ref[1:] - off_ref[:-1])).all(), (w.name, mode)
+            flags, want = hip.check_edges(q_ref, off_ref, D.GH_CHECK_ENV, BAD)
+            assert (first == want).all(), (w.name, mode)                  # the same samples: the same first failures
+            dev = torch.device("cuda", 0)
+            q_t = torch.zeros((n + 8, hip.dof), dtype=torch.float32 if prec == 32 else torch.float64, device=dev)
+            off_t = torch.zeros(E + 1, dtype=torch.int32, device=dev)
+            cnt_t = torch.zeros(E, dtype=torch.int32, device=dev)
+            flags_t = torch.zeros(n + 8, dtype=torch.uint8, device=dev)
+            first_t = torch.zeros(E, dtype=torch.int32, device=dev)
+            hip.check_edges_from_endpoints_dev(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), q_t, off_t, cnt_t, flags_t,
+                                               first_t, 0.1, 4096, mode, D.GH_CHECK_ENV, BAD)
+            torch.cuda.synchronize()
+            assert q_t[:n].cpu().numpy().tobytes() == q_ref.tobytes(), (w.name, mode)
