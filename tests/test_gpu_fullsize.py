@@ -206,3 +206,23 @@ def test_exact_capacity_grows_when_regions_run_full():
     assert caps[0] == 16 and caps[1] == 32 and caps[2] == 64 and caps[-1] in (64, 128, 256)
     assert full[0] > 1000 and full[-1] == 0
     assert caps[-1] == caps[-2]                                          # it stops growing once nothing is full
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_exact_stage_windows_and_waiting_entries(prec):
+    """The 6-DOF arm among 256 boxes and cylinders hands 1.9 entries per configuration to the exact stage.  With tiles
+    of 32 sweep wavefronts a workgroup then holds ~3900 entries — many tiles more than one window of 4096 — and most
+    windows hold enough later entries for them to wait for the first ones' answers: every such schedule (tile 8, 16, 32)
+    must give the fused kernel's bytes."""
+    w = W.ur10_workload(256)
+    n = 200000 + 11
+    ref = engine.Scene(w.robot_keep, w.obstacle_keep, w.margin, prec)
+    q = w.configs(n, seed=77, dtype=ref.dtype, overshoot=0.005)
+    want = ref.check_batch(q, BOTH | D.GH_PATH_FUSED)
+    ref.check_batch(q, BOTH | D.GH_COUNT_CANDIDATES)
+    st = ref.pipeline_last_stats()
+    assert st["exact_items"] > 1.2 * n and st["redo_waves"] == 0, st         # several entries per configuration
+    for tile in (8, 16, 32):
+        hip = _scene_with_env(w, prec, GEAR_HIP_N2_TILE=tile)
+        assert (hip.check_batch(q, BOTH | D.GH_PATH_PIPELINE) == want).all(), tile
+        assert (hip.check_batch(q, D.GH_CHECK_ENV | D.GH_PATH_PIPELINE) == (want & 5)).all(), tile
